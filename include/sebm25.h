@@ -1,0 +1,262 @@
+/*
+ * sebm25.h — C ABI of the MI355X (gfx950) BM25 index-build and top-k scoring library.
+ *
+ * The reference project has no FFI: its hot path is SQL text executed by PostgreSQL from two
+ * Python callables.  Each entry point below names the reference statement(s) it replaces
+ * (paths are relative to the reference checkout).  A Python host binds these with ctypes; the
+ * signatures use plain pointers and sizes only.
+ *
+ * Conventions
+ *  - Every function returns 0 (SEBM25_OK) or a positive SEBM25_E_* code and never throws.
+ *    sebm25_last_error() returns a human-readable message for the last failing call on the
+ *    handle (or, with a NULL handle, for the last failing call on the calling thread).
+ *  - Array arguments may point to host memory or to device memory of the handle's GPU; the
+ *    library detects which (hipPointerGetAttributes).  Host arrays are staged through HBM by
+ *    the library; device arrays are used in place.
+ *  - Calls are blocking: results are complete when the call returns.  A handle may be used
+ *    from one thread at a time (calls on one handle are serialised by an internal mutex).
+ *  - "unit" means a web document id (documents.id) for source 1 or a dense news-article index
+ *    for source 2; the two id spaces are separate.
+ */
+#ifndef SEBM25_H
+#define SEBM25_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sebm25_index sebm25_index;
+
+enum {
+    SEBM25_OK = 0,
+    SEBM25_E_INVALID = 1,  /* bad argument (NULL pointer, zero vocabulary, unknown flag, ...)   */
+    SEBM25_E_RANGE = 2,    /* a value does not fit: term_id >= n_terms, unit >= n_units,        */
+                           /* invalid meta byte, tf or ids too wide for the packed row          */
+    SEBM25_E_HIP = 3,      /* a HIP runtime call failed                                         */
+    SEBM25_E_NOMEM = 4,    /* device or host allocation failed                                  */
+    SEBM25_E_STATE = 5,    /* call order violated (e.g. search before build)                    */
+    SEBM25_E_ORDER = 6,    /* rows were declared unit-major but are not                         */
+    SEBM25_E_INTERNAL = 7
+};
+
+/* tokens.source_type values (alembic/versions/0007_unify_news_tokens.py:19-27). */
+#define SEBM25_SRC_WEB 1u
+#define SEBM25_SRC_NEWS 2u
+/* tokens.field values written by the crawler (app/crawler/worker.py:230-234). */
+#define SEBM25_FIELD_TITLE 1u
+#define SEBM25_FIELD_DESCRIPTION 2u
+#define SEBM25_FIELD_BODY 4u
+/* meta byte of a row: source_type | field << 2. */
+#define SEBM25_META(source_type, field) ((uint8_t)((source_type) | ((field) << 2)))
+
+/* sebm25_rows.flags */
+#define SEBM25_ROWS_UNIT_MAJOR 1u /* rows are ordered by (source_type, unit): all web rows first in
+                                     ascending doc id, then all news rows in ascending article
+                                     index (any order inside one unit).  Lets the build sort on
+                                     term_id alone.  Verified on device; a violation returns
+                                     SEBM25_E_ORDER.  Without the flag the build sorts on
+                                     (term, source, unit). */
+/* doc_flags bits */
+#define SEBM25_DOC_DONE 1u    /* documents.status = 'done'                                       */
+#define SEBM25_DOC_WC_NULL 2u /* documents.word_count IS NULL (skipped by AVG)                   */
+
+/*
+ * The `tokens` table as structure-of-arrays (alembic/versions/0001_initial_schema.py:65-74,
+ * 0007_unify_news_tokens.py:19-27; writers app/crawler/worker.py:229-239 and
+ * app/batch/news_fetcher.py:303-311), plus the two `documents` columns the job reads
+ * (0001_initial_schema.py:42,45).  The TEXT term <-> term_id dictionary stays on the host.
+ */
+typedef struct sebm25_rows {
+    const uint32_t* term_id;    /* [n_rows] dense term index, < n_terms                          */
+    const uint32_t* unit_id;    /* [n_rows] doc id (web rows) or article index (news rows)       */
+    const uint32_t* tf;         /* [n_rows] tokens.frequency                                     */
+    const uint8_t* meta;        /* [n_rows] SEBM25_META(source_type, field)                      */
+    uint64_t n_rows;            /* R, at most 2^32 - 2                                           */
+    uint32_t n_terms;           /* V >= 1                                                        */
+    uint32_t n_docs;            /* size of the web doc id space (rows of `documents`)            */
+    uint32_t n_articles;        /* size of the news article index space                          */
+    const uint32_t* word_count; /* [n_docs] documents.word_count, or NULL: use the per-doc sum
+                                   of tf over body rows computed by the build                    */
+    const uint8_t* doc_flags;   /* [n_docs] SEBM25_DOC_* bits, or NULL: every doc is 'done' and
+                                   has a word_count                                              */
+    uint32_t flags;             /* SEBM25_ROWS_*                                                 */
+} sebm25_rows;
+
+/* Local (this shard's) counts produced by sebm25_build_local and consumed by sebm25_finalize.
+ * All fields are plain sums over documents, so shards combine by addition. */
+typedef struct sebm25_doc_totals {
+    uint64_t n_done;    /* COUNT(*) WHERE status='done'            (app/batch/bm25_stats.py:12)  */
+    uint64_t n_wc;      /* done docs with non-NULL word_count      (denominator of AVG, :9)      */
+    uint64_t sum_wc;    /* SUM(word_count) over those docs         (numerator of AVG, :9)        */
+    uint64_t n_postings;/* unique (term, unit) pairs kept in this shard's index (web + news)     */
+} sebm25_doc_totals;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+
+/* Creates an empty index bound to GPU `device`.  No counterpart in the reference (its state
+ * is the PostgreSQL database reached through app/common/db.py:22-32). */
+int sebm25_create(int device, sebm25_index** out);
+void sebm25_destroy(sebm25_index* ix);
+const char* sebm25_last_error(const sebm25_index* ix);
+/* All work of this handle is enqueued on `hip_stream` (a hipStream_t; NULL = the default
+ * stream, which is also PyTorch's default on ROCm). */
+int sebm25_set_stream(sebm25_index* ix, void* hip_stream);
+
+/* ---- index build: replaces app/batch/bm25_stats.py:9-27 ---------------------------------- */
+
+/*
+ * Sorts the rows by (term, source, unit), collapses the up-to-three field rows of one
+ * (term, unit) into one posting and builds the CSR inverted index; computes this shard's
+ *   df[t]   = COUNT(DISTINCT doc_id) over web rows of t            (bm25_stats.py:20,23-24)
+ *   totals  = the three document aggregates of bm25_stats.py:9,12
+ *   doc_len = per web doc, sum of tf over its body (field 4) rows.
+ * Posting weight (search_service.py:19-27 and :84-87): web  w = sum_f tf_f * W[f],
+ * W = {1: 3.2, 2: 1.7, else 1.0}; news w = sum tf; summed in double, stored as float.
+ * Postings of web docs that are not 'done' are counted in df (bm25_stats.py has no status
+ * filter on tokens) but left out of the index (search_service.py:32).
+ */
+int sebm25_build_local(sebm25_index* ix, const sebm25_rows* rows);
+
+/* Copies this shard's df (uint32[n_terms]) and totals out, e.g. into buffers that a
+ * collective then sums across shards. */
+int sebm25_local_stats(sebm25_index* ix, uint32_t* df_out, sebm25_doc_totals* totals_out);
+
+/*
+ * Completes the statistics from corpus-wide sums (NULL = use this shard's own):
+ *   N     = n_done, or 1 when n_done = 0                           (bm25_stats.py:13)
+ *   avgdl = sum_wc / n_wc, or 0.0 when n_wc = 0                    (bm25_stats.py:9-10)
+ *   idf_t = LN((N - df_t + 0.5) / (df_t + 0.5) + 1)                (bm25_stats.py:21)
+ * evaluated in double as log1p((N - df + 0.5) / (df + 0.5)).
+ */
+int sebm25_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* totals_global);
+
+/* sebm25_build_local followed by sebm25_finalize(ix, NULL, NULL): the whole single-GPU job. */
+int sebm25_build(sebm25_index* ix, const sebm25_rows* rows);
+
+/*
+ * The content of `term_statistics` (0001_initial_schema.py:110-115; INSERT at
+ * bm25_stats.py:18-26): per term doc_frequency and idf, plus the scalar N and avg_doc_len that
+ * every row repeats.  term_rows[t] = number of input rows of term t; the reference inserts a
+ * row only for terms with term_rows > 0.  Any output pointer may be NULL.
+ */
+int sebm25_get_stats(sebm25_index* ix, uint32_t* df_out, double* idf_out, uint32_t* term_rows_out,
+                     uint64_t* n_docs_out, double* avgdl_out);
+
+/* Per web doc sum of tf over body rows (uint32[n_docs]). */
+int sebm25_get_doc_len(sebm25_index* ix, uint32_t* doc_len_out);
+
+/*
+ * Replaces the idf used for scoring: idf_used[t] = present[t] ? idf[t] : 1.0, which is
+ * COALESCE(ts.idf, 1.0) of search_service.py:21,47,86 for a term_statistics table that may
+ * lag behind `tokens`.  present == NULL means every term is present.
+ */
+int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present);
+
+/* Tie-break key per unit, ascending = better: the rank of the unit's url in the ORDER BY
+ * url ASC collation (search_service.py:38,99).  NULL restores the default, the global unit id.
+ * `source` is SEBM25_SRC_WEB or SEBM25_SRC_NEWS; rank has n_docs or n_articles entries. */
+int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank);
+
+/* Added to local unit ids in search results (document-sharded indexes). */
+int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base);
+
+/* Sizes of the built index. */
+typedef struct sebm25_index_info {
+    uint64_t n_rows;
+    uint64_t n_postings;      /* kept postings, web + news */
+    uint64_t n_web_postings;
+    uint32_t n_terms, n_docs, n_articles;
+    uint32_t term_bits, unit_bits, tf_bits; /* packed sort row layout */
+    uint32_t sort_passes;
+} sebm25_index_info;
+int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
+
+/*
+ * Copies the CSR out (any pointer may be NULL): for term t, web postings are
+ * [row_ptr[t], news_ptr[t]) and news postings [news_ptr[t], row_ptr[t+1]), each in ascending
+ * unit order.  row_ptr has n_terms + 1 entries, news_ptr n_terms, post_* n_postings.
+ */
+int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit,
+                        float* post_weight);
+
+/* ---- scoring + top-k: replaces the SQL executed at app/api/search_service.py:319-320 and
+ *      :351-352 (SEARCH_SQL :13-40, FALLBACK_SEARCH_SQL :42-66, NEWS_SEARCH_SQL :68-101) ------ */
+
+/*
+ * Batched scoring.  Query q has term ids q_terms[q_offsets[q] .. q_offsets[q+1]) (host arrays);
+ * duplicate ids count once and ids >= n_terms match nothing (`t.term = ANY($1)`).
+ * For each unit with at least one matching posting of the requested source:
+ *   score   = sum over query terms (in the order given) of idf_used[t] * w(t, unit)   (double)
+ *   matched = COUNT(DISTINCT t.term)
+ * Results are ordered score DESC, url rank ASC and cut at k (`LIMIT $2`), k <= 2048.
+ * Outputs (host or device, caller-allocated): out_unit/out_score/out_matched/out_tie hold
+ * n_queries * k entries, row q filled for the first out_count[q] slots; the rest is padded
+ * with unit 0xFFFFFFFF, score 0, matched 0.  out_tie (the tie-break key of each result, needed
+ * to merge shards) may be NULL.
+ */
+int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets,
+                  uint32_t n_queries, uint32_t k, uint32_t* out_unit, double* out_score,
+                  uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count);
+
+/*
+ * Merges n_lists per-shard result sets (the layout sebm25_search writes, concatenated list by
+ * list: in_x[(l * n_queries + q) * k + i], in_count[l * n_queries + q]) into one top-k per
+ * query with the same ordering.  Device or host pointers.  The reference's counterpart is the
+ * single shared database doing ORDER BY ... LIMIT over all rows (search_service.py:38-39).
+ */
+int sebm25_merge_topk(sebm25_index* ix, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                      const uint32_t* in_unit, const double* in_score, const uint32_t* in_matched,
+                      const uint32_t* in_tie, const uint32_t* in_count, uint32_t* out_unit,
+                      double* out_score, uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+
+/* Device time of each phase of the last build / search on this handle, from HIP events on the
+ * handle's stream.  names_out receives pointers to static strings.  Returns the number of
+ * phases through *n_out (at most cap are written). */
+int sebm25_get_timings(sebm25_index* ix, const char** names_out, float* ms_out, uint32_t cap, uint32_t* n_out);
+/* Timing events are recorded only while enabled (default off; they add a few us per phase). */
+int sebm25_enable_timing(sebm25_index* ix, int on);
+
+/* ---- synthetic corpus (measurement and tests; no counterpart in the reference) ----------- */
+
+typedef struct sebm25_corpus_spec {
+    uint64_t seed;
+    uint32_t n_terms;      /* V                                                                  */
+    uint32_t doc_begin;    /* web docs [doc_begin, doc_end) of the global corpus are generated,  */
+    uint32_t doc_end;      /* with unit ids local to the shard (doc - doc_begin)                 */
+    uint32_t article_begin;/* news articles [article_begin, article_end)                         */
+    uint32_t article_end;
+    double zipf_s;         /* term rank r drawn with p(r) ~ r^-zipf_s; term_id = r - 1           */
+    uint32_t body_min;     /* body length L ~ U{body_min .. body_max} draws                      */
+    uint32_t body_max;
+    uint32_t title_len;    /* draws in the title field                                           */
+    uint32_t desc_len;     /* draws in the description field                                     */
+} sebm25_corpus_spec;
+
+/* Fills cdf[n_terms] (host) with the 32-bit fixed-point cumulative Zipf distribution the
+ * generators sample from. */
+int sebm25_zipf_cdf(uint32_t n_terms, double zipf_s, uint32_t* cdf_out);
+
+/*
+ * Generates the shard's rows directly in HBM.  First call with all output pointers NULL to
+ * get *n_rows_out; then call again with device buffers of that many entries (word_count:
+ * doc_end - doc_begin entries).  Rows come out unit-major: web docs ascending, then articles;
+ * inside a unit by field (1, 2, 4) then ascending term id.
+ */
+int sebm25_gen_corpus(sebm25_index* ix, const sebm25_corpus_spec* spec, uint64_t* n_rows_out,
+                      uint32_t* term_id, uint32_t* unit_id, uint32_t* tf, uint8_t* meta,
+                      uint32_t* word_count);
+
+/* Generates n_queries queries of terms_per_query distinct term ids drawn from the same Zipf
+ * law restricted to ranks >= min_rank (host output, n_queries * terms_per_query entries). */
+int sebm25_gen_queries(uint64_t seed, uint32_t n_terms, double zipf_s, uint32_t min_rank,
+                       uint32_t n_queries, uint32_t terms_per_query, uint32_t* q_terms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEBM25_H */

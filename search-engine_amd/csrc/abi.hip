@@ -1,0 +1,863 @@
+// Host side of the C ABI declared in include/sebm25.h: argument checking, device memory,
+// the build / search pipelines as sequences of kernel launches, and result copies.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+using namespace sebm25;
+
+namespace {
+thread_local std::string g_thread_err;
+
+constexpr uint32_t MAX_K = 2048;
+constexpr uint32_t MAX_QUERY_TERMS = 64;
+constexpr uint32_t SORT_MAX_CHUNKS = 512;
+constexpr uint32_t RED_MAX_CHUNKS = 1024;
+}  // namespace
+
+struct sebm25_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::mutex mu;
+    bool built = false, finalized = false;
+
+    uint64_t R = 0;
+    uint32_t V = 0, n_docs = 0, n_articles = 0;
+    RowFmt fmt{1, 1, 59};
+    uint32_t n_pass = 0;
+    uint64_t P = 0, WH = 0;
+    uint32_t web_base = 0, news_base = 0;
+    sebm25_doc_totals local_totals{}, used_totals{};
+    uint64_t N = 1;
+    double avgdl = 0.0;
+
+    DevBuf sortA, sortB, chunk_hist, scan_tmp, chunk_counts;
+    DevBuf row_ptr, news_ptr, wh_ptr, rs_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
+    DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc; u32 err at [7]
+    DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
+    DevBuf url_rank_web, url_rank_news;
+    bool has_rank_web = false, has_rank_news = false, has_df_global = false;
+    uint32_t* post_unit = nullptr;
+    float* post_w = nullptr;
+
+    std::vector<uint32_t> h_row_ptr, h_news_ptr;
+    bool host_ptrs_valid = false;
+
+    // search scratch
+    DevBuf q_items, q_terms, q_first, q_n;
+    DevBuf o_unit, o_score, o_mat, o_tie, o_count, t_unit, t_score, t_mat, t_tie, t_count;
+    DevBuf m_in[5];
+    DevBuf gen_rows, gen_cdf;
+
+    PhaseTimer timer;
+};
+
+namespace {
+
+int fail(sebm25_index* ix, int code, const std::string& msg) {
+    if (ix) ix->err = msg;
+    g_thread_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ix, expr)                                                                             \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            (void)hipGetLastError();                                                                  \
+            return fail(ix, e__ == hipErrorOutOfMemory ? SEBM25_E_NOMEM : SEBM25_E_HIP,               \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                          \
+        }                                                                                             \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int bits_for(uint64_t n_values) {  // bits needed to hold 0 .. n_values - 1
+    int b = 1;
+    while (b < 64 && (1ull << b) < n_values) ++b;
+    return b;
+}
+
+// device view of a caller array: in place when it already lives on the GPU, else staged
+template <class T>
+int stage_in(sebm25_index* ix, const T* src, size_t n, DevBuf& buf, const T** out) {
+    if (n == 0 || !src) {
+        *out = nullptr;
+        return SEBM25_OK;
+    }
+    if (is_device_ptr(src)) {
+        *out = src;
+        return SEBM25_OK;
+    }
+    HIP_TRY(ix, buf.ensure(n * sizeof(T)));
+    HIP_TRY(ix, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ix->stream));
+    *out = buf.as<T>();
+    return SEBM25_OK;
+}
+
+int copy_out(sebm25_index* ix, void* dst, const void* src_dev, size_t bytes) {
+    if (!dst || bytes == 0) return SEBM25_OK;
+    HIP_TRY(ix, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, ix->stream));
+    return SEBM25_OK;
+}
+
+void phase_begin(sebm25_index* ix, const char* name) {
+    PhaseTimer& t = ix->timer;
+    if (!t.enabled) return;
+    if (t.ev.size() < 2 * (t.used + 1)) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        t.ev.push_back(a);
+        t.ev.push_back(b);
+    }
+    if (t.names.size() <= t.used) t.names.push_back(name); else t.names[t.used] = name;
+    (void)hipEventRecord(t.ev[2 * t.used], ix->stream);
+}
+void phase_end(sebm25_index* ix) {
+    PhaseTimer& t = ix->timer;
+    if (!t.enabled) return;
+    (void)hipEventRecord(t.ev[2 * t.used + 1], ix->stream);
+    ++t.used;
+}
+void phases_reset(sebm25_index* ix) { ix->timer.used = 0; }
+void phases_collect(sebm25_index* ix) {
+    PhaseTimer& t = ix->timer;
+    if (!t.enabled) return;
+    t.ms.assign(t.used, 0.f);
+    for (size_t i = 0; i < t.used; ++i) {
+        (void)hipEventSynchronize(t.ev[2 * i + 1]);
+        (void)hipEventElapsedTime(&t.ms[i], t.ev[2 * i], t.ev[2 * i + 1]);
+    }
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int refresh_host_ptrs(sebm25_index* ix) {
+    if (ix->host_ptrs_valid) return SEBM25_OK;
+    ix->h_row_ptr.resize((size_t)ix->V + 1);
+    ix->h_news_ptr.resize(ix->V);
+    HIP_TRY(ix, hipMemcpyAsync(ix->h_row_ptr.data(), ix->row_ptr.p, ((size_t)ix->V + 1) * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(ix->h_news_ptr.data(), ix->news_ptr.p, (size_t)ix->V * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    ix->host_ptrs_valid = true;
+    return SEBM25_OK;
+}
+
+int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* tg) {
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "finalize: no index built on this handle");
+    const uint32_t* df_dev = ix->df_local.as<uint32_t>();
+    ix->has_df_global = false;
+    if (df_global) {
+        HIP_TRY(ix, ix->df_global.ensure((size_t)ix->V * 4));
+        HIP_TRY(ix, hipMemcpyAsync(ix->df_global.p, df_global, (size_t)ix->V * 4, hipMemcpyDefault, ix->stream));
+        df_dev = ix->df_global.as<uint32_t>();
+        ix->has_df_global = true;
+    }
+    ix->used_totals = tg ? *tg : ix->local_totals;
+    ix->N = ix->used_totals.n_done ? ix->used_totals.n_done : 1;  // `or 1`
+    ix->avgdl = ix->used_totals.n_wc ? (double)ix->used_totals.sum_wc / (double)ix->used_totals.n_wc : 0.0;  // `or 0.0`
+    phase_begin(ix, "idf");
+    launch_idf(df_dev, ix->V, ix->N, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    ix->finalized = true;
+    return SEBM25_OK;
+}
+
+int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
+    if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
+    if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
+    if (in->n_rows > 0xFFFFFFFEull) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 2 rows in one shard");
+    if (in->n_rows && (!in->term_id || !in->unit_id || !in->tf || !in->meta))
+        return fail(ix, SEBM25_E_INVALID, "build: a row array is NULL");
+    if (in->flags & ~SEBM25_ROWS_UNIT_MAJOR) return fail(ix, SEBM25_E_INVALID, "build: unknown flag");
+
+    ix->built = ix->finalized = false;
+    ix->host_ptrs_valid = false;
+    const uint64_t R = in->n_rows;
+    const uint32_t V = in->n_terms;
+    RowFmt fmt;
+    fmt.term_bits = bits_for(V);
+    fmt.unit_bits = bits_for(std::max<uint64_t>(std::max(in->n_docs, in->n_articles), 1));
+    fmt.tf_bits = 61 - fmt.term_bits - fmt.unit_bits;
+    if (fmt.tf_bits < 8)
+        return fail(ix, SEBM25_E_RANGE, "build: term and unit id spaces leave fewer than 8 bits for tf in the packed row");
+    ix->R = R; ix->V = V; ix->n_docs = in->n_docs; ix->n_articles = in->n_articles; ix->fmt = fmt;
+    phases_reset(ix);
+
+    // ---- device memory
+    const size_t Rcap = std::max<uint64_t>(R, 1);
+    HIP_TRY(ix, ix->sortA.ensure(Rcap * 8));
+    HIP_TRY(ix, ix->sortB.ensure(Rcap * 8));
+    HIP_TRY(ix, ix->row_ptr.ensure(((size_t)V + 1) * 4));
+    HIP_TRY(ix, ix->news_ptr.ensure((size_t)V * 4));
+    HIP_TRY(ix, ix->wh_ptr.ensure(((size_t)V + 1) * 4));
+    HIP_TRY(ix, ix->rs_ptr.ensure(((size_t)V + 1) * 4));
+    HIP_TRY(ix, ix->df_local.ensure((size_t)V * 4));
+    HIP_TRY(ix, ix->term_rows.ensure((size_t)V * 4));
+    HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
+    HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
+    HIP_TRY(ix, ix->doc_len.ensure(std::max<size_t>(in->n_docs, 1) * 4));
+    HIP_TRY(ix, ix->scalars.ensure(64));
+    HIP_TRY(ix, hipMemsetAsync(ix->scalars.p, 0, 64, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(ix->doc_len.p, 0, std::max<size_t>(in->n_docs, 1) * 4, ix->stream));
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
+
+    // ---- inputs
+    RawRows raw{};
+    const uint32_t* wc_dev = nullptr;
+    const uint8_t* flags_dev = nullptr;
+    int rc;
+    if ((rc = stage_in(ix, in->term_id, R, ix->st_term, &raw.term))) return rc;
+    if ((rc = stage_in(ix, in->unit_id, R, ix->st_unit, &raw.unit))) return rc;
+    if ((rc = stage_in(ix, in->tf, R, ix->st_tf, &raw.tf))) return rc;
+    if ((rc = stage_in(ix, in->meta, R, ix->st_meta, &raw.meta))) return rc;
+    if ((rc = stage_in(ix, in->word_count, in->n_docs, ix->st_wc, &wc_dev))) return rc;
+    if ((rc = stage_in(ix, in->doc_flags, in->n_docs, ix->st_flags, &flags_dev))) return rc;
+
+    uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
+    uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
+
+    if (R == 0) {
+        HIP_TRY(ix, hipMemsetAsync(row_ptr, 0, ((size_t)V + 1) * 4, ix->stream));
+        HIP_TRY(ix, hipMemsetAsync(news_ptr, 0, (size_t)V * 4, ix->stream));
+        HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
+        HIP_TRY(ix, hipMemsetAsync(ix->term_rows.p, 0, (size_t)V * 4, ix->stream));
+        ix->post_unit = ix->sortA.as<uint32_t>();
+        ix->post_w = reinterpret_cast<float*>(ix->sortA.as<uint32_t>() + 1);
+        ix->n_pass = 0;
+    } else {
+        // ---- stable LSD radix sort on the key bits of the packed row
+        const bool unit_major = (in->flags & SEBM25_ROWS_UNIT_MAJOR) != 0;
+        const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
+        const int key_bits = 64 - key_lo;
+        const int n_pass = (key_bits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+        ix->n_pass = (uint32_t)n_pass;
+        uint32_t G = (uint32_t)std::min<uint64_t>((R + SORT_TILE - 1) / SORT_TILE, SORT_MAX_CHUNKS);
+        uint64_t chunk_rows = (R + G - 1) / G;
+        chunk_rows = (chunk_rows + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
+        G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
+        const size_t hist_words = (size_t)SORT_MAX_BINS * G;
+        HIP_TRY(ix, ix->chunk_hist.ensure(hist_words * 4));
+        HIP_TRY(ix, ix->scan_tmp.ensure(scan_tmp_words(hist_words) * 4));
+
+        BuildCtx ctx{};
+        ctx.fmt = fmt;
+        ctx.n_terms = V; ctx.n_docs = in->n_docs; ctx.n_articles = in->n_articles;
+        ctx.check_order = unit_major ? 1u : 0u;
+        ctx.doc_len = ix->doc_len.as<uint32_t>();
+        ctx.err = err_dev;
+
+        static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6"};
+        static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6"};
+        static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6"};
+
+        const uint64_t* src_packed = nullptr;
+        uint64_t* bufs[2] = {ix->sortA.as<uint64_t>(), ix->sortB.as<uint64_t>()};
+        int shift = key_lo;
+        for (int p = 0; p < n_pass; ++p) {
+            const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
+            const int mode = p == 0 ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
+            uint64_t* dst = bufs[p & 1];
+            const size_t words = ((size_t)1 << bits) * G;
+            phase_begin(ix, hist_names[p]);
+            launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, ix->chunk_hist.as<uint32_t>(), ix->stream);
+            phase_end(ix);
+            phase_begin(ix, scan_names[p]);
+            launch_exclusive_scan_u32(ix->chunk_hist.as<uint32_t>(), words, ix->scan_tmp.as<uint32_t>(), ix->stream);
+            phase_end(ix);
+            phase_begin(ix, scat_names[p]);
+            launch_sort_scatter(mode, raw, src_packed, dst, R, chunk_rows, G, shift, bits, ctx, ix->chunk_hist.as<uint32_t>(), ix->stream);
+            phase_end(ix);
+            src_packed = dst;
+            shift += bits;
+        }
+        HIP_TRY(ix, hipGetLastError());
+        const uint64_t* sorted = src_packed;
+        uint64_t* other = bufs[n_pass & 1];  // the buffer the last pass did not write
+        // postings live in the free sort buffer: unit ids in its first half, weights in the second
+        ix->post_unit = reinterpret_cast<uint32_t*>(other);
+        ix->post_w = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(other) + Rcap);
+
+        // ---- segmented reduction into postings
+        uint32_t G2 = (uint32_t)std::min<uint64_t>((R + RED_TILE - 1) / RED_TILE, RED_MAX_CHUNKS);
+        uint64_t chunk2 = (R + G2 - 1) / G2;
+        chunk2 = (chunk2 + RED_TILE - 1) / RED_TILE * RED_TILE;
+        G2 = (uint32_t)((R + chunk2 - 1) / chunk2);
+        HIP_TRY(ix, ix->chunk_counts.ensure((size_t)G2 * 8));
+        HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
+        phase_begin(ix, "reduce_count");
+        launch_reduce_count(sorted, R, chunk2, G2, fmt, flags_dev, ix->chunk_counts.as<uint64_t>(), ix->stream);
+        phase_end(ix);
+        phase_begin(ix, "reduce_emit");
+        launch_reduce_emit(sorted, R, chunk2, G2, fmt, flags_dev, ix->chunk_counts.as<uint64_t>(), V, ix->post_unit,
+                           ix->post_w, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal,
+                           ix->stream);
+        phase_end(ix);
+        phase_begin(ix, "term_stats");
+        launch_term_stats(V, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(),
+                          ix->df_local.as<uint32_t>(), ix->term_rows.as<uint32_t>(), ix->stream);
+        phase_end(ix);
+    }
+    phase_begin(ix, "doc_stats");
+    launch_doc_stats(wc_dev, ix->doc_len.as<uint32_t>(), flags_dev, in->n_docs, scal + 2, ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+
+    uint64_t h[8];
+    HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    const uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    if (dev_err & DEV_ERR_RANGE)
+        return fail(ix, SEBM25_E_RANGE, "build: a row has term_id >= n_terms, a unit id outside its id space, an invalid "
+                                        "source_type, or a tf too wide for the packed row");
+    if (dev_err & DEV_ERR_ORDER)
+        return fail(ix, SEBM25_E_ORDER, "build: rows were declared unit-major (SEBM25_ROWS_UNIT_MAJOR) but are not");
+    ix->P = h[0];
+    ix->WH = h[1];
+    ix->local_totals.n_done = h[2];
+    ix->local_totals.n_wc = h[3];
+    ix->local_totals.sum_wc = h[4];
+    ix->local_totals.n_postings = h[0];
+    ix->built = true;
+    return SEBM25_OK;
+}
+
+}  // namespace
+
+// ============================================================================ C ABI =======
+
+extern "C" {
+
+const char* sebm25_last_error(const sebm25_index* ix) { return ix ? ix->err.c_str() : g_thread_err.c_str(); }
+
+int sebm25_create(int device, sebm25_index** out) {
+    if (!out) return fail(nullptr, SEBM25_E_INVALID, "create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, SEBM25_E_HIP, "create: no HIP device is visible");
+    }
+    if (device < 0 || device >= n) return fail(nullptr, SEBM25_E_INVALID, "create: device index out of range");
+    sebm25_index* ix = new (std::nothrow) sebm25_index();
+    if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
+    ix->device = device;
+    *out = ix;
+    return SEBM25_OK;
+}
+
+void sebm25_destroy(sebm25_index* ix) {
+    if (!ix) return;
+    {
+        DeviceGuard g(ix->device);
+        (void)hipStreamSynchronize(ix->stream);
+        DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->scan_tmp, &ix->chunk_counts, &ix->row_ptr, &ix->news_ptr,
+                         &ix->wh_ptr, &ix->rs_ptr, &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
+                         &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
+                         &ix->st_flags, &ix->st_misc, &ix->url_rank_web, &ix->url_rank_news, &ix->q_items, &ix->q_terms,
+                         &ix->q_first, &ix->q_n, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
+                         &ix->t_score, &ix->t_mat, &ix->t_tie, &ix->t_count, &ix->m_in[0], &ix->m_in[1], &ix->m_in[2],
+                         &ix->m_in[3], &ix->m_in[4], &ix->gen_rows, &ix->gen_cdf};
+        for (DevBuf* b : all) b->release();
+        for (hipEvent_t e : ix->timer.ev) (void)hipEventDestroy(e);
+    }
+    delete ix;
+}
+
+int sebm25_set_stream(sebm25_index* ix, void* hip_stream) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "set_stream: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return SEBM25_OK;
+}
+
+int sebm25_enable_timing(sebm25_index* ix, int on) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "enable_timing: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->timer.enabled = on != 0;
+    ix->timer.used = 0;
+    return SEBM25_OK;
+}
+
+int sebm25_get_timings(sebm25_index* ix, const char** names_out, float* ms_out, uint32_t cap, uint32_t* n_out) {
+    if (!ix || !n_out) return fail(ix, SEBM25_E_INVALID, "get_timings: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    phases_collect(ix);
+    const uint32_t n = (uint32_t)ix->timer.ms.size();
+    *n_out = n;
+    for (uint32_t i = 0; i < n && i < cap; ++i) {
+        if (names_out) names_out[i] = ix->timer.names[i];
+        if (ms_out) ms_out[i] = ix->timer.ms[i];
+    }
+    return SEBM25_OK;
+}
+
+int sebm25_build_local(sebm25_index* ix, const sebm25_rows* rows) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "build_local: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    return do_build_local(ix, rows);
+}
+
+int sebm25_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* totals_global) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "finalize: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    return do_finalize(ix, df_global, totals_global);
+}
+
+int sebm25_build(sebm25_index* ix, const sebm25_rows* rows) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "build: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = do_build_local(ix, rows);
+    if (rc) return rc;
+    return do_finalize(ix, nullptr, nullptr);
+}
+
+int sebm25_local_stats(sebm25_index* ix, uint32_t* df_out, sebm25_doc_totals* totals_out) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "local_stats: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "local_stats: no index built on this handle");
+    int rc = copy_out(ix, df_out, ix->df_local.p, (size_t)ix->V * 4);
+    if (rc) return rc;
+    if (totals_out) *totals_out = ix->local_totals;
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+int sebm25_get_stats(sebm25_index* ix, uint32_t* df_out, double* idf_out, uint32_t* term_rows_out, uint64_t* n_docs_out,
+                     double* avgdl_out) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_stats: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->finalized) return fail(ix, SEBM25_E_STATE, "get_stats: statistics are not finalized");
+    int rc;
+    if ((rc = copy_out(ix, df_out, ix->has_df_global ? ix->df_global.p : ix->df_local.p, (size_t)ix->V * 4))) return rc;
+    if ((rc = copy_out(ix, idf_out, ix->idf.p, (size_t)ix->V * 8))) return rc;
+    if ((rc = copy_out(ix, term_rows_out, ix->term_rows.p, (size_t)ix->V * 4))) return rc;
+    if (n_docs_out) *n_docs_out = ix->N;
+    if (avgdl_out) *avgdl_out = ix->avgdl;
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+int sebm25_get_doc_len(sebm25_index* ix, uint32_t* doc_len_out) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_doc_len: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_doc_len: no index built on this handle");
+    int rc = copy_out(ix, doc_len_out, ix->doc_len.p, (size_t)ix->n_docs * 4);
+    if (rc) return rc;
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present) {
+    if (!ix || !idf) return fail(ix, SEBM25_E_INVALID, "set_idf: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "set_idf: no index built on this handle");
+    const double* idf_dev = nullptr;
+    const uint8_t* pr_dev = nullptr;
+    int rc;
+    if ((rc = stage_in(ix, idf, ix->V, ix->st_misc, &idf_dev))) return rc;
+    if ((rc = stage_in(ix, present, ix->V, ix->st_flags, &pr_dev))) return rc;
+    launch_idf_override(idf_dev, pr_dev, ix->V, ix->idf_used.as<double>(), ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    ix->finalized = true;
+    return SEBM25_OK;
+}
+
+int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "set_url_rank: handle is NULL");
+    if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
+        return fail(ix, SEBM25_E_INVALID, "set_url_rank: source must be 1 (web) or 2 (news)");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "set_url_rank: no index built on this handle");
+    const bool web = source == (int)SEBM25_SRC_WEB;
+    bool& has = web ? ix->has_rank_web : ix->has_rank_news;
+    if (!rank) {
+        has = false;
+        return SEBM25_OK;
+    }
+    DevBuf& buf = web ? ix->url_rank_web : ix->url_rank_news;
+    const size_t n = web ? ix->n_docs : ix->n_articles;
+    HIP_TRY(ix, buf.ensure(std::max<size_t>(n, 1) * 4));
+    HIP_TRY(ix, hipMemcpyAsync(buf.p, rank, n * 4, hipMemcpyDefault, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    has = true;
+    return SEBM25_OK;
+}
+
+int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "set_unit_base: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->web_base = web_base;
+    ix->news_base = news_base;
+    return SEBM25_OK;
+}
+
+int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
+    if (!ix || !out) return fail(ix, SEBM25_E_INVALID, "get_info: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_info: no index built on this handle");
+    int rc = refresh_host_ptrs(ix);
+    if (rc) return rc;
+    uint64_t web = 0;
+    for (uint32_t t = 0; t < ix->V; ++t) web += ix->h_news_ptr[t] - ix->h_row_ptr[t];
+    out->n_rows = ix->R;
+    out->n_postings = ix->P;
+    out->n_web_postings = web;
+    out->n_terms = ix->V;
+    out->n_docs = ix->n_docs;
+    out->n_articles = ix->n_articles;
+    out->term_bits = (uint32_t)ix->fmt.term_bits;
+    out->unit_bits = (uint32_t)ix->fmt.unit_bits;
+    out->tf_bits = (uint32_t)ix->fmt.tf_bits;
+    out->sort_passes = ix->n_pass;
+    return SEBM25_OK;
+}
+
+int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit, float* post_weight) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_postings: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_postings: no index built on this handle");
+    int rc = refresh_host_ptrs(ix);
+    if (rc) return rc;
+    // row pointers are widened on the host (the ABI promises 64-bit offsets)
+    if (row_ptr) {
+        if (is_device_ptr(row_ptr)) return fail(ix, SEBM25_E_INVALID, "get_postings: row_ptr must be a host array");
+        for (size_t t = 0; t <= ix->V; ++t) row_ptr[t] = ix->h_row_ptr[t];
+    }
+    if (news_ptr) {
+        if (is_device_ptr(news_ptr)) return fail(ix, SEBM25_E_INVALID, "get_postings: news_ptr must be a host array");
+        for (size_t t = 0; t < ix->V; ++t) news_ptr[t] = ix->h_news_ptr[t];
+    }
+    if ((rc = copy_out(ix, post_unit, ix->post_unit, (size_t)ix->P * 4))) return rc;
+    if ((rc = copy_out(ix, post_weight, ix->post_w, (size_t)ix->P * 4))) return rc;
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+// ---------------------------------------------------------------------------- search -------
+
+int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
+                  uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie,
+                  uint32_t* out_count) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built || !ix->finalized) return fail(ix, SEBM25_E_STATE, "search: index is not built and finalized");
+    if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
+        return fail(ix, SEBM25_E_INVALID, "search: source must be 1 (web) or 2 (news)");
+    if (k == 0 || k > MAX_K) return fail(ix, SEBM25_E_RANGE, "search: k must be in 1..2048");
+    if (n_queries == 0) return SEBM25_OK;
+    if (!q_offsets || !out_unit || !out_score || !out_matched || !out_count)
+        return fail(ix, SEBM25_E_INVALID, "search: NULL argument");
+    if (is_device_ptr(q_offsets) || is_device_ptr(q_terms))
+        return fail(ix, SEBM25_E_INVALID, "search: query arrays must be host memory");
+    if (q_offsets[n_queries] && !q_terms) return fail(ix, SEBM25_E_INVALID, "search: q_terms is NULL");
+    int rc = refresh_host_ptrs(ix);
+    if (rc) return rc;
+    phases_reset(ix);
+
+    const bool news = source == (int)SEBM25_SRC_NEWS;
+    const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
+    const std::vector<uint32_t>&rp = ix->h_row_ptr, &np = ix->h_news_ptr;
+    auto list_len = [&](uint32_t t) -> uint64_t { return news ? rp[t + 1] - np[t] : np[t] - rp[t]; };
+
+    // ---- plan: distinct valid terms per query, then split long queries by unit range
+    std::vector<uint32_t> flat;          // deduped terms of all queries
+    std::vector<uint32_t> q_toff(n_queries), q_nt(n_queries);
+    std::vector<uint64_t> q_len(n_queries);
+    flat.reserve(q_offsets[n_queries]);
+    uint64_t total_len = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        if (q_offsets[q + 1] < q_offsets[q]) return fail(ix, SEBM25_E_INVALID, "search: q_offsets must be non-decreasing");
+        const size_t start = flat.size();
+        uint64_t len = 0;
+        for (uint64_t j = q_offsets[q]; j < q_offsets[q + 1]; ++j) {
+            const uint32_t t = q_terms[j];
+            if (t >= ix->V || list_len(t) == 0) continue;  // matches no row
+            bool dup = false;
+            for (size_t x = start; x < flat.size(); ++x) dup |= flat[x] == t;
+            if (dup) continue;  // `= ANY($1)`: a repeated term selects its rows once
+            flat.push_back(t);
+            len += list_len(t);
+        }
+        if (flat.size() - start > MAX_QUERY_TERMS)
+            return fail(ix, SEBM25_E_RANGE, "search: more than 64 distinct matching terms in one query");
+        q_toff[q] = (uint32_t)start;
+        q_nt[q] = (uint32_t)(flat.size() - start);
+        q_len[q] = len;
+        total_len += len;
+    }
+    // postings per work item: enough items to fill the GPU, few enough that per-item set-up
+    // (binary searches, final cut) stays small next to the streaming
+    uint64_t slice = std::min<uint64_t>(std::max<uint64_t>(total_len / 8192, 8192), 131072);
+    slice = std::max<uint64_t>(slice, (uint64_t)k * 32);
+    struct Planned { QItem it; uint64_t len; };
+    std::vector<Planned> plan;
+    plan.reserve(n_queries);
+    std::vector<uint32_t> first(n_queries, 0), nlists(n_queries, 0);
+    uint32_t n_tmp = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        uint32_t ns = (uint32_t)std::min<uint64_t>((q_len[q] + slice - 1) / slice, 64);
+        ns = std::max(1u, std::min(ns, std::max(1u, n_units / 4096u)));
+        if (ns > 1) {
+            first[q] = n_tmp;
+            nlists[q] = ns;
+        }
+        for (uint32_t s = 0; s < ns; ++s) {
+            QItem it{};
+            it.q = q;
+            it.term_off = q_toff[q];
+            it.n_terms = q_nt[q];
+            it.unit_lo = (uint32_t)((uint64_t)n_units * s / ns);
+            it.unit_hi = s + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (s + 1) / ns);
+            it.direct = ns == 1;
+            it.out_slot = ns == 1 ? q : n_tmp++;
+            plan.push_back({it, q_len[q] / ns});
+        }
+    }
+    std::stable_sort(plan.begin(), plan.end(), [](const Planned& a, const Planned& b) { return a.len > b.len; });
+    std::vector<QItem> items(plan.size());
+    for (size_t i = 0; i < plan.size(); ++i) items[i] = plan[i].it;
+
+    // ---- device buffers
+    const size_t qk = (size_t)n_queries * k, tk = (size_t)std::max(n_tmp, 1u) * k;
+    const bool dev_out = is_device_ptr(out_unit);
+    if (dev_out != is_device_ptr(out_score) || dev_out != is_device_ptr(out_matched) || dev_out != is_device_ptr(out_count) ||
+        (out_tie && dev_out != is_device_ptr(out_tie)))
+        return fail(ix, SEBM25_E_INVALID, "search: output arrays must be all host or all device memory");
+    HIP_TRY(ix, ix->q_items.ensure(items.size() * sizeof(QItem)));
+    HIP_TRY(ix, ix->q_terms.ensure(std::max<size_t>(flat.size(), 1) * 4));
+    HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->t_unit.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_score.ensure(tk * 8));
+    HIP_TRY(ix, ix->t_mat.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_tie.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(n_tmp, 1u) * 4));
+    HIP_TRY(ix, ix->o_tie.ensure(qk * 4));
+    uint32_t *d_unit = out_unit, *d_mat = out_matched, *d_count = out_count, *d_tie = out_tie;
+    double* d_score = out_score;
+    if (!dev_out) {
+        HIP_TRY(ix, ix->o_unit.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_score.ensure(qk * 8));
+        HIP_TRY(ix, ix->o_mat.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_count.ensure((size_t)n_queries * 4));
+        d_unit = ix->o_unit.as<uint32_t>();
+        d_score = ix->o_score.as<double>();
+        d_mat = ix->o_mat.as<uint32_t>();
+        d_count = ix->o_count.as<uint32_t>();
+        d_tie = ix->o_tie.as<uint32_t>();
+    } else if (!d_tie) {
+        d_tie = ix->o_tie.as<uint32_t>();
+    }
+    phase_begin(ix, "search_plan_h2d");
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_items.p, items.data(), items.size() * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
+    if (!flat.empty())
+        HIP_TRY(ix, hipMemcpyAsync(ix->q_terms.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_first.p, first.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_n.p, nlists.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    phase_end(ix);
+
+    ScoreArgs a{};
+    a.row_ptr = ix->row_ptr.as<uint32_t>();
+    a.news_ptr = ix->news_ptr.as<uint32_t>();
+    a.post_unit = ix->post_unit;
+    a.post_w = ix->post_w;
+    a.idf_used = ix->idf_used.as<double>();
+    a.url_rank = news ? (ix->has_rank_news ? ix->url_rank_news.as<uint32_t>() : nullptr)
+                      : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);
+    a.unit_base = news ? ix->news_base : ix->web_base;
+    a.news = news ? 1 : 0;
+    a.items = ix->q_items.as<QItem>();
+    a.q_terms = ix->q_terms.as<uint32_t>();
+    a.n_items = (uint32_t)items.size();
+    a.k = k;
+    a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
+    a.tmp_unit = ix->t_unit.as<uint32_t>(); a.tmp_score = ix->t_score.as<double>(); a.tmp_matched = ix->t_mat.as<uint32_t>();
+    a.tmp_tie = ix->t_tie.as<uint32_t>(); a.tmp_count = ix->t_count.as<uint32_t>();
+    phase_begin(ix, "score_topk");
+    launch_score(a, ix->stream);
+    phase_end(ix);
+    if (n_tmp) {
+        MergeArgs m{};
+        m.n_queries = n_queries; m.k = k;
+        m.first = ix->q_first.as<uint32_t>(); m.n = ix->q_n.as<uint32_t>();
+        m.in_unit = a.tmp_unit; m.in_score = a.tmp_score; m.in_matched = a.tmp_matched; m.in_tie = a.tmp_tie; m.in_count = a.tmp_count;
+        m.list_stride = 1;
+        m.out_unit = d_unit; m.out_score = d_score; m.out_matched = d_mat; m.out_tie = d_tie; m.out_count = d_count;
+        phase_begin(ix, "merge_slices");
+        launch_merge(m, ix->stream);
+        phase_end(ix);
+    }
+    HIP_TRY(ix, hipGetLastError());
+    if (!dev_out) {
+        if ((rc = copy_out(ix, out_unit, d_unit, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_score, d_score, qk * 8))) return rc;
+        if ((rc = copy_out(ix, out_matched, d_mat, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_tie, d_tie, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_count, d_count, (size_t)n_queries * 4))) return rc;
+    }
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+int sebm25_merge_topk(sebm25_index* ix, uint32_t n_lists, uint32_t n_queries, uint32_t k, const uint32_t* in_unit,
+                      const double* in_score, const uint32_t* in_matched, const uint32_t* in_tie, const uint32_t* in_count,
+                      uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "merge_topk: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (k == 0 || k > MAX_K) return fail(ix, SEBM25_E_RANGE, "merge_topk: k must be in 1..2048");
+    if (n_queries == 0) return SEBM25_OK;
+    if (n_lists == 0 || !in_unit || !in_score || !in_matched || !in_tie || !in_count || !out_unit || !out_score ||
+        !out_matched || !out_count)
+        return fail(ix, SEBM25_E_INVALID, "merge_topk: NULL argument or no lists");
+    const size_t lk_n = (size_t)n_lists * n_queries * k, qk = (size_t)n_queries * k;
+    MergeArgs m{};
+    int rc;
+    if ((rc = stage_in(ix, in_unit, lk_n, ix->m_in[0], &m.in_unit))) return rc;
+    if ((rc = stage_in(ix, in_score, lk_n, ix->m_in[1], &m.in_score))) return rc;
+    if ((rc = stage_in(ix, in_matched, lk_n, ix->m_in[2], &m.in_matched))) return rc;
+    if ((rc = stage_in(ix, in_tie, lk_n, ix->m_in[3], &m.in_tie))) return rc;
+    if ((rc = stage_in(ix, in_count, (size_t)n_lists * n_queries, ix->m_in[4], &m.in_count))) return rc;
+    const bool dev_out = is_device_ptr(out_unit);
+    if (dev_out != is_device_ptr(out_score) || dev_out != is_device_ptr(out_matched) || dev_out != is_device_ptr(out_count) ||
+        (out_tie && dev_out != is_device_ptr(out_tie)))
+        return fail(ix, SEBM25_E_INVALID, "merge_topk: output arrays must be all host or all device memory");
+    uint32_t *d_unit = out_unit, *d_mat = out_matched, *d_count = out_count, *d_tie = out_tie;
+    double* d_score = out_score;
+    if (!dev_out) {
+        HIP_TRY(ix, ix->o_unit.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_score.ensure(qk * 8));
+        HIP_TRY(ix, ix->o_mat.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_tie.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_count.ensure((size_t)n_queries * 4));
+        d_unit = ix->o_unit.as<uint32_t>();
+        d_score = ix->o_score.as<double>();
+        d_mat = ix->o_mat.as<uint32_t>();
+        d_tie = ix->o_tie.as<uint32_t>();
+        d_count = ix->o_count.as<uint32_t>();
+    }
+    // lists of query q: q, q + n_queries, q + 2 n_queries, ...
+    std::vector<uint32_t> first(n_queries), nl(n_queries, n_lists);
+    for (uint32_t q = 0; q < n_queries; ++q) first[q] = q;
+    HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_first.p, first.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_n.p, nl.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    m.n_queries = n_queries; m.k = k;
+    m.first = ix->q_first.as<uint32_t>(); m.n = ix->q_n.as<uint32_t>();
+    m.list_stride = n_queries;
+    m.out_unit = d_unit; m.out_score = d_score; m.out_matched = d_mat; m.out_tie = d_tie; m.out_count = d_count;
+    launch_merge(m, ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    if (!dev_out) {
+        if ((rc = copy_out(ix, out_unit, d_unit, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_score, d_score, qk * 8))) return rc;
+        if ((rc = copy_out(ix, out_matched, d_mat, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_tie, d_tie, qk * 4))) return rc;
+        if ((rc = copy_out(ix, out_count, d_count, (size_t)n_queries * 4))) return rc;
+    }
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+// ---------------------------------------------------------------------------- corpus -------
+
+int sebm25_zipf_cdf(uint32_t n_terms, double zipf_s, uint32_t* cdf_out) {
+    if (!cdf_out || n_terms == 0) return fail(nullptr, SEBM25_E_INVALID, "zipf_cdf: NULL output or empty vocabulary");
+    host_zipf_cdf(n_terms, zipf_s, cdf_out);
+    return SEBM25_OK;
+}
+
+int sebm25_gen_queries(uint64_t seed, uint32_t n_terms, double zipf_s, uint32_t min_rank, uint32_t n_queries,
+                       uint32_t terms_per_query, uint32_t* q_terms_out) {
+    if (!q_terms_out || n_terms == 0) return fail(nullptr, SEBM25_E_INVALID, "gen_queries: NULL output or empty vocabulary");
+    std::vector<uint32_t> cdf(n_terms);
+    host_zipf_cdf(n_terms, zipf_s, cdf.data());
+    if (host_gen_queries(seed, n_terms, cdf.data(), min_rank, n_queries, terms_per_query, q_terms_out))
+        return fail(nullptr, SEBM25_E_RANGE, "gen_queries: vocabulary too small for terms_per_query distinct terms");
+    return SEBM25_OK;
+}
+
+int sebm25_gen_corpus(sebm25_index* ix, const sebm25_corpus_spec* spec, uint64_t* n_rows_out, uint32_t* term_id,
+                      uint32_t* unit_id, uint32_t* tf, uint8_t* meta, uint32_t* word_count) {
+    if (!ix || !spec || !n_rows_out) return fail(ix, SEBM25_E_INVALID, "gen_corpus: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (spec->n_terms == 0 || spec->doc_end < spec->doc_begin || spec->article_end < spec->article_begin ||
+        spec->body_max < spec->body_min)
+        return fail(ix, SEBM25_E_INVALID, "gen_corpus: inconsistent spec");
+    if ((uint64_t)spec->title_len + spec->desc_len + spec->body_max > gen_max_draws())
+        return fail(ix, SEBM25_E_RANGE, "gen_corpus: title_len + desc_len + body_max exceeds 1024 draws");
+    const uint64_t n_units = (uint64_t)(spec->doc_end - spec->doc_begin) + (spec->article_end - spec->article_begin);
+    if (n_units == 0) {
+        *n_rows_out = 0;
+        return SEBM25_OK;
+    }
+    if (n_units > 0x7FFFFFFFull) return fail(ix, SEBM25_E_RANGE, "gen_corpus: too many units");
+    std::vector<uint32_t> cdf(spec->n_terms);
+    host_zipf_cdf(spec->n_terms, spec->zipf_s, cdf.data());
+    HIP_TRY(ix, ix->gen_cdf.ensure((size_t)spec->n_terms * 4));
+    HIP_TRY(ix, hipMemcpyAsync(ix->gen_cdf.p, cdf.data(), (size_t)spec->n_terms * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, ix->gen_rows.ensure((n_units + 1) * 4));
+    HIP_TRY(ix, ix->scan_tmp.ensure(scan_tmp_words(n_units + 1) * 4));
+    uint32_t* unit_rows = ix->gen_rows.as<uint32_t>();
+    HIP_TRY(ix, hipMemsetAsync(unit_rows + n_units, 0, 4, ix->stream));
+    launch_gen_count(*spec, ix->gen_cdf.as<uint32_t>(), unit_rows, ix->stream);
+    // exclusive scan over n_units + 1 words: the last word becomes the row total
+    launch_exclusive_scan_u32(unit_rows, n_units + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    uint32_t total = 0;
+    HIP_TRY(ix, hipMemcpyAsync(&total, unit_rows + n_units, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    *n_rows_out = total;
+    if (!term_id && !unit_id && !tf && !meta) return SEBM25_OK;
+    if (!term_id || !unit_id || !tf || !meta) return fail(ix, SEBM25_E_INVALID, "gen_corpus: pass all row arrays or none");
+    if (!is_device_ptr(term_id) || !is_device_ptr(unit_id) || !is_device_ptr(tf) || !is_device_ptr(meta) ||
+        (word_count && !is_device_ptr(word_count)))
+        return fail(ix, SEBM25_E_INVALID, "gen_corpus: output arrays must be device memory");
+    launch_gen_emit(*spec, ix->gen_cdf.as<uint32_t>(), unit_rows, term_id, unit_id, tf, meta, word_count, ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+}  // extern "C"

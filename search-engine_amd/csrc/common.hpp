@@ -1,0 +1,186 @@
+// Internal declarations shared by the host side (abi.hip) and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sebm25.h"
+
+namespace sebm25 {
+
+// ------------------------------------------------------------------ packed sort row ------
+// One token row as a 64-bit word, most significant field first:
+//   [ term : Tb ][ src : 1 ][ unit : Ub ][ fc : 2 ][ tf : Fb ]      Tb + Ub + Fb = 61
+// src: 0 web, 1 news.  fc: 0 = weight 1.0, 1 = title (3.2), 2 = description (1.7).
+// Sorting on the top Tb + 1 + Ub bits orders rows by (term, source, unit).
+struct RowFmt {
+    int term_bits, unit_bits, tf_bits;
+    __host__ __device__ int term_shift() const { return 64 - term_bits; }
+    __host__ __device__ int src_shift() const { return 63 - term_bits; }
+    __host__ __device__ int unit_shift() const { return tf_bits + 2; }
+    __host__ __device__ int key_shift() const { return tf_bits + 2; }
+    __host__ __device__ uint64_t pack(uint32_t term, uint32_t src, uint32_t unit, uint32_t fc, uint64_t tf) const {
+        return ((uint64_t)term << term_shift()) | ((uint64_t)src << src_shift()) | ((uint64_t)unit << unit_shift()) |
+               ((uint64_t)fc << tf_bits) | tf;
+    }
+    __host__ __device__ uint32_t term(uint64_t r) const { return (uint32_t)(r >> term_shift()); }
+    __host__ __device__ uint32_t src(uint64_t r) const { return (uint32_t)(r >> src_shift()) & 1u; }
+    __host__ __device__ uint32_t unit(uint64_t r) const {
+        return (uint32_t)(r >> unit_shift()) & (uint32_t)((1ull << unit_bits) - 1ull);
+    }
+    __host__ __device__ uint32_t fc(uint64_t r) const { return (uint32_t)(r >> tf_bits) & 3u; }
+    __host__ __device__ uint64_t tf(uint64_t r) const { return r & ((1ull << tf_bits) - 1ull); }
+    __host__ __device__ uint64_t key(uint64_t r) const { return r >> key_shift(); }
+};
+
+// device error bits raised by kernels
+enum : uint32_t { DEV_ERR_RANGE = 1u, DEV_ERR_ORDER = 2u };
+
+struct RawRows {
+    const uint32_t* term;
+    const uint32_t* unit;
+    const uint32_t* tf;
+    const uint8_t* meta;
+};
+
+// grow-only device allocation
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + (bytes >> 4) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PhaseTimer {
+    std::vector<const char*> names;
+    std::vector<hipEvent_t> ev;  // 2 per phase
+    std::vector<float> ms;
+    bool enabled = false;
+    size_t used = 0;
+};
+
+// sort tile geometry (shared by host planning and kernels)
+constexpr int SORT_THREADS = 512;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+constexpr int SORT_MAX_BITS = 10;
+constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
+
+constexpr int RED_THREADS = 256;
+constexpr int RED_ITEMS = 8;
+constexpr int RED_TILE = RED_THREADS * RED_ITEMS;
+
+struct BuildCtx {
+    RowFmt fmt;
+    uint32_t n_terms, n_docs, n_articles;
+    uint32_t check_order;   // rows declared unit-major: verify
+    uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
+    uint32_t* err;          // device error word
+};
+
+// ---- launchers implemented in the .hip files (all asynchronous on `st`) ----
+// sort_mode: 0 raw rows, digit taken from term_id alone; 1 raw rows, digit from the packed
+// key; 2 packed rows.
+void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
+                      int shift, int bits, const BuildCtx& ctx, uint32_t* chunk_hist, hipStream_t st);
+void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
+                         uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
+                         const uint32_t* chunk_off, hipStream_t st);
+// in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
+size_t scan_tmp_words(size_t n);
+void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
+
+void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
+                         const uint8_t* doc_flags, uint64_t* chunk_counts, hipStream_t st);
+void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
+                        const uint8_t* doc_flags, const uint64_t* chunk_counts, uint32_t n_terms,
+                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
+                        uint32_t* wh_ptr, uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st);
+void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
+                       const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows, hipStream_t st);
+void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
+                      uint32_t n_docs, uint64_t* totals3 /* n_done, n_wc, sum_wc (zeroed) */, hipStream_t st);
+void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, double* idf, double* idf_used, hipStream_t st);
+void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_terms, double* idf_used,
+                         hipStream_t st);
+
+// scoring
+struct QItem {
+    uint32_t q;         // query index
+    uint32_t term_off;  // into the flattened term list
+    uint32_t n_terms;   // 1..64
+    uint32_t unit_lo, unit_hi;
+    uint32_t out_slot;  // result list index (direct output row or temporary slice list)
+    uint32_t direct;    // 1: writes the final result row
+    uint32_t pad;
+};
+struct ScoreArgs {
+    const uint32_t* row_ptr;
+    const uint32_t* news_ptr;
+    const uint32_t* post_unit;
+    const float* post_w;
+    const double* idf_used;
+    const uint32_t* url_rank;  // may be null
+    uint32_t unit_base;
+    int news;  // 0 web, 1 news
+    const QItem* items;
+    const uint32_t* q_terms;  // flattened, deduped, valid
+    uint32_t n_items;
+    uint32_t k;
+    // outputs: final rows [n_queries][k] and temporary slice lists [n_slices][k]
+    uint32_t *out_unit, *out_matched, *out_tie, *out_count;
+    double* out_score;
+    uint32_t *tmp_unit, *tmp_matched, *tmp_tie, *tmp_count;
+    double* tmp_score;
+};
+void launch_score(const ScoreArgs& a, hipStream_t st);
+struct MergeArgs {
+    uint32_t n_queries, k;
+    // per query: lists [first[q], first[q] + n[q]) of the input set; n[q] == 0 -> leave output alone
+    const uint32_t* first;
+    const uint32_t* n;
+    const uint32_t *in_unit, *in_matched, *in_tie, *in_count;
+    const double* in_score;
+    uint32_t list_stride;  // distance (in lists) between consecutive lists of one query
+    uint32_t *out_unit, *out_matched, *out_tie, *out_count;
+    double* out_score;
+};
+void launch_merge(const MergeArgs& a, hipStream_t st);
+
+// synthetic corpus
+uint32_t gen_max_draws();
+void launch_gen_count(const sebm25_corpus_spec& spec, const uint32_t* cdf, uint32_t* unit_rows, hipStream_t st);
+void launch_gen_emit(const sebm25_corpus_spec& spec, const uint32_t* cdf, const uint32_t* row_off,
+                     uint32_t* term_id, uint32_t* unit_id, uint32_t* tf, uint8_t* meta, uint32_t* word_count,
+                     hipStream_t st);
+void host_zipf_cdf(uint32_t n_terms, double zipf_s, uint32_t* cdf_out);
+int host_gen_queries(uint64_t seed, uint32_t n_terms, const uint32_t* cdf, uint32_t min_rank, uint32_t n_queries,
+                     uint32_t tpq, uint32_t* out);
+
+}  // namespace sebm25

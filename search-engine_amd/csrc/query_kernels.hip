@@ -1,0 +1,291 @@
+// Batched scoring + top-k for gfx950.  Replaces the scoring statements the reference sends to
+// PostgreSQL (app/api/search_service.py:13-40 web, :42-66 fallback, :68-101 news):
+//   score(unit) = SUM over query terms of idf_used[t] * w(t, unit),  matched = COUNT(DISTINCT term),
+//   ORDER BY score DESC, url ASC LIMIT k.
+//
+// One wavefront owns one work item = (query, range of unit ids).  Posting lists are sorted by
+// unit, so the wave walks all lists of the query in step through a window of WIN consecutive
+// unit ids whose accumulators live in LDS: 64 coalesced postings per list per load, a
+// "touched" bitmap (one 32-bit word per lane) instead of clearing accumulators, and a
+// candidate buffer that is cut back to the best k by a wave-wide bitonic sort whenever it
+// fills.  Lists are added in query-term order, so a score is the same double sum whatever the
+// work split.  No workgroup barriers: a wave's LDS operations complete in issue order.
+#include "common.hpp"
+
+namespace sebm25 {
+
+namespace {
+
+constexpr int WIN = 2048;  // unit ids per window = 64 lanes x 32 bitmap bits
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// order-preserving map double -> uint64 (larger double = larger key); every finite value > 0
+__device__ __forceinline__ uint64_t score_key(double s) {
+    const uint64_t b = (uint64_t)__double_as_longlong(s);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_score(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+// "a ranks before b": score DESC, then tie-break key ASC
+__device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, uint32_t tb) {
+    return ka > kb || (ka == kb && ta < tb);
+}
+
+// Candidate buffer of one wave (LDS).  Slots [0, n) are live; after cut() they are sorted best
+// first and n <= k.
+template <int CAP>
+struct TopK {
+    uint64_t* key;
+    uint32_t* tie;
+    uint32_t* unit;
+    uint32_t* mat;
+    uint32_t n;
+    uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
+    uint32_t thr_tie;
+
+    __device__ void init(unsigned char* lds) {
+        key = reinterpret_cast<uint64_t*>(lds);
+        tie = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
+        unit = tie + CAP;
+        mat = unit + CAP;
+        n = 0;
+        thr_key = 0;
+        thr_tie = 0xFFFFFFFFu;
+    }
+    static constexpr size_t bytes() { return (size_t)CAP * 20; }
+
+    // wave-wide bitonic sort of all CAP slots (dead slots hold the worst key), best first
+    __device__ void cut(uint32_t k) {
+        const uint32_t lane = lane_id();
+        for (uint32_t i = n + lane; i < CAP; i += 64) {
+            key[i] = 0;
+            tie[i] = 0xFFFFFFFFu;
+            unit[i] = 0xFFFFFFFFu;
+            mat[i] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t size = 2; size <= CAP; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t e = lane; e < CAP / 2; e += 64) {
+                    const uint32_t lo = ((e & ~(stride - 1)) << 1) | (e & (stride - 1));
+                    const uint32_t hi = lo | stride;
+                    const bool desc = (lo & size) == 0;  // block direction
+                    const uint64_t klo = key[lo], khi = key[hi];
+                    const uint32_t tlo = tie[lo], thi = tie[hi];
+                    const bool hi_first = better(khi, thi, klo, tlo);
+                    if (hi_first == desc) {
+                        key[lo] = khi;
+                        key[hi] = klo;
+                        tie[lo] = thi;
+                        tie[hi] = tlo;
+                        const uint32_t ul = unit[lo], uh = unit[hi];
+                        unit[lo] = uh;
+                        unit[hi] = ul;
+                        const uint32_t ml = mat[lo], mh = mat[hi];
+                        mat[lo] = mh;
+                        mat[hi] = ml;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (n > k) n = k;
+        if (n == k && k > 0) {
+            thr_key = key[k - 1];
+            thr_tie = tie[k - 1];
+        }
+    }
+
+    // every lane may offer one candidate; wave-uniform control flow
+    __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
+        bool pass = has && better(ck, ct, thr_key, thr_tie);
+        uint64_t pm = __ballot(pass);
+        if (pm == 0) return;
+        if (n + (uint32_t)__popcll(pm) > CAP) {
+            cut(k);
+            pass = has && better(ck, ct, thr_key, thr_tie);
+            pm = __ballot(pass);
+        }
+        if (pass) {
+            const uint32_t pos = n + (uint32_t)__popcll(pm & lanemask_lt());
+            key[pos] = ck;
+            tie[pos] = ct;
+            unit[pos] = cu;
+            mat[pos] = cm;
+        }
+        n += (uint32_t)__popcll(pm);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ void write_out(uint32_t k, uint32_t* o_unit, double* o_score, uint32_t* o_mat, uint32_t* o_tie,
+                              uint32_t* o_count) {
+        cut(k);
+        for (uint32_t i = lane_id(); i < k; i += 64) {
+            const bool live = i < n;
+            o_unit[i] = live ? unit[i] : 0xFFFFFFFFu;
+            o_score[i] = live ? key_score(key[i]) : 0.0;
+            o_mat[i] = live ? mat[i] : 0u;
+            if (o_tie) o_tie[i] = live ? tie[i] : 0xFFFFFFFFu;
+        }
+        if (lane_id() == 0) *o_count = n;
+    }
+};
+
+// first index in [b, e) whose unit is >= x (per-lane binary search in global memory)
+__device__ __forceinline__ uint32_t lower_bound_unit(const uint32_t* post_unit, uint32_t b, uint32_t e, uint32_t x) {
+    while (b < e) {
+        const uint32_t mid = b + ((e - b) >> 1);
+        if (post_unit[mid] < x) b = mid + 1; else e = mid;
+    }
+    return b;
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
+    __shared__ __align__(16) double acc[WIN];
+    __shared__ unsigned char cnt[WIN];
+    __shared__ uint32_t touched[WIN / 32];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+
+    const QItem it = a.items[blockIdx.x];
+    const uint32_t lane = lane_id();
+    const uint32_t T = it.n_terms;
+
+    // lane t < T keeps the cursor of list t
+    uint32_t my_cur = 0, my_end = 0;
+    double my_idf = 0.0;
+    if (lane < T) {
+        const uint32_t term = a.q_terms[it.term_off + lane];
+        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+        my_end = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
+        my_idf = a.idf_used[term];
+    }
+    touched[lane] = 0;
+    TopK<CAP> tk;
+    tk.init(topk_mem);
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        // window start: the smallest unit any list still has to deliver
+        uint32_t nxt = (lane < T && my_cur < my_end) ? a.post_unit[my_cur] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor(nxt, off));
+        if (nxt == 0xFFFFFFFFu) break;
+        const uint32_t base = nxt & ~31u;
+        const uint64_t wend = (uint64_t)base + WIN;
+
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t c = __shfl(my_cur, (int)t);
+            const uint32_t e = __shfl(my_end, (int)t);
+            const double idf = __shfl(my_idf, (int)t);
+            while (true) {
+                const uint32_t i = c + lane;
+                const bool valid = i < e;
+                const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
+                const bool in = valid && (uint64_t)u < wend;
+                const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                if (in) {
+                    const double v = __dmul_rn(idf, (double)a.post_w[i]);
+                    const uint32_t idx = u - base;
+                    const uint32_t bit = 1u << (idx & 31u);
+                    const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                    if (old & bit) {
+                        acc[idx] = __dadd_rn(acc[idx], v);
+                        cnt[idx] = (unsigned char)(cnt[idx] + 1);
+                    } else {
+                        acc[idx] = v;
+                        cnt[idx] = 1;
+                    }
+                }
+                c += n_in;
+                if (n_in < 64) break;
+            }
+            if (lane == t) my_cur = c;
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // harvest the window: lane l owns units [base + 32 l, base + 32 l + 32)
+        uint32_t word = touched[lane];
+        touched[lane] = 0;
+        while (__ballot(word != 0)) {
+            const bool has = word != 0;
+            const uint32_t b = has ? (uint32_t)__ffs((int)word) - 1u : 0u;
+            word &= word - 1u;
+            const uint32_t idx = lane * 32u + b;
+            double s = 0.0;
+            uint32_t m = 0, unit = 0, tie = 0;
+            if (has) {
+                s = acc[idx];
+                m = cnt[idx];
+                unit = base + idx;
+                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+            }
+            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
+        }
+    }
+
+    const size_t o = (size_t)it.out_slot * a.k;
+    if (it.direct)
+        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                     a.out_count + it.out_slot);
+    else
+        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+}
+
+// one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
+template <int CAP>
+__global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+    const uint32_t q = blockIdx.x;
+    const uint32_t nl = a.n[q];
+    if (nl == 0) return;
+    TopK<CAP> tk;
+    tk.init(topk_mem);
+    const uint32_t lane = lane_id();
+    for (uint32_t l = 0; l < nl; ++l) {
+        const size_t list = (size_t)a.first[q] + (size_t)l * a.list_stride;
+        const uint32_t c = min(a.in_count[list], a.k);
+        for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool has = i < c;
+            const size_t o = list * a.k + i;
+            const double s = has ? a.in_score[o] : 0.0;
+            tk.offer(has, score_key(s), has ? a.in_tie[o] : 0u, has ? a.in_unit[o] : 0u, has ? a.in_matched[o] : 0u, a.k);
+        }
+    }
+    const size_t o = (size_t)q * a.k;
+    tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                 a.out_count + q);
+}
+
+}  // namespace
+
+void launch_score(const ScoreArgs& a, hipStream_t st) {
+    if (a.n_items == 0) return;
+    dim3 grid(a.n_items), block(64);
+    if (a.k <= 64)
+        hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, a);
+    else if (a.k <= 256)
+        hipLaunchKernelGGL(k_score<512>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(k_score<4096>, grid, block, 0, st, a);
+}
+
+void launch_merge(const MergeArgs& a, hipStream_t st) {
+    if (a.n_queries == 0) return;
+    dim3 grid(a.n_queries), block(64);
+    if (a.k <= 64)
+        hipLaunchKernelGGL(k_merge<128>, grid, block, 0, st, a);
+    else if (a.k <= 256)
+        hipLaunchKernelGGL(k_merge<512>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(k_merge<4096>, grid, block, 0, st, a);
+}
+
+}  // namespace sebm25

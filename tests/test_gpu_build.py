@@ -1,0 +1,150 @@
+"""GPU parity: index build through the C ABI against the CPU oracle (bit-exact integers)."""
+import numpy as np
+import pytest
+
+import search_engine_amd as se
+from oracle import oracle as O
+
+from helpers import assert_build_matches, gpu_build, oracle_index, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_docs,n_terms,n_articles", [(300, 2000, 0), (2000, 5000, 150), (64, 37, 5), (1, 3, 0)])
+def test_build_matches_oracle(gpu_index_factory, n_docs, n_terms, n_articles):
+    c = small_corpus(n_docs=n_docs, n_terms=n_terms, n_articles=n_articles)
+    orc = oracle_index(c)
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    assert_build_matches(ix, orc)
+    info = ix.info()
+    assert info.n_rows == len(c["term_id"])
+    assert info.n_postings == orc.totals.n_postings
+
+
+def test_build_10k_docs_two_passes(gpu_index_factory):
+    # BASELINE config 1 size: 10k docs, 500k-term vocabulary -> 19 term bits, two radix passes
+    c = small_corpus(n_docs=10_000, n_terms=500_000, n_articles=500)
+    orc = oracle_index(c)
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    assert ix.info().sort_passes == 2
+    assert_build_matches(ix, orc)
+
+
+def test_unsorted_rows_full_key_sort(gpu_index_factory):
+    c = small_corpus(n_docs=500, n_terms=3000, n_articles=40)
+    orc = oracle_index(c)
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(len(c["term_id"]))
+    shuffled = dict(c)
+    for key in ("term_id", "unit_id", "tf", "meta"):
+        shuffled[key] = np.ascontiguousarray(c[key][perm])
+    ix = gpu_index_factory()
+    with pytest.raises(se.Sebm25Error) as e:
+        gpu_build(ix, shuffled, unit_major=True)
+    assert e.value.code == 6  # SEBM25_E_ORDER
+    gpu_build(ix, shuffled, unit_major=False)
+    # rows of one (term, unit) are summed in input order: after a shuffle the float weights can
+    # differ in the last bit, everything integer stays exact
+    st = ix.stats()
+    np.testing.assert_array_equal(st["df"], orc.df)
+    np.testing.assert_array_equal(st["term_rows"], orc.term_rows)
+    np.testing.assert_array_equal(ix.doc_len(), orc.doc_len)
+    rp, nps, pu, pw = ix.postings()
+    np.testing.assert_array_equal(rp, orc.row_ptr)
+    np.testing.assert_array_equal(nps, orc.news_ptr)
+    np.testing.assert_array_equal(pu, orc.post_unit)
+    np.testing.assert_allclose(pw, orc.post_weight, rtol=2e-7)
+    orc2 = oracle_index(shuffled)
+    np.testing.assert_array_equal(pw.view(np.uint32), orc2.post_weight.view(np.uint32))
+
+
+def test_doc_flags_and_null_word_count(gpu_index_factory):
+    c = small_corpus(n_docs=400, n_terms=1500, n_articles=30)
+    rng = np.random.default_rng(3)
+    flags = np.where(rng.random(400) < 0.8, se.DOC_DONE, 0).astype(np.uint8)
+    flags |= np.where(rng.random(400) < 0.1, se.DOC_WC_NULL, 0).astype(np.uint8)
+    orc = oracle_index(c, doc_flags=flags)
+    ix = gpu_index_factory()
+    gpu_build(ix, c, doc_flags=flags)
+    assert_build_matches(ix, orc)
+    # df counts docs of any status, the index keeps only 'done' docs
+    assert int(orc.df.sum()) > ix.info().n_web_postings
+
+
+def test_word_count_from_rows_when_absent(gpu_index_factory):
+    c = small_corpus(n_docs=200, n_terms=800)
+    orc = oracle_index(c, word_count=None)
+    ix = gpu_index_factory()
+    gpu_build(ix, c, word_count=None)
+    assert_build_matches(ix, orc)
+    np.testing.assert_array_equal(ix.doc_len(), c["word_count"])  # synthetic rule: word_count = sum tf over body rows
+
+
+def test_empty_and_degenerate(gpu_index_factory):
+    ix = gpu_index_factory()
+    z32, z8 = np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+    ix.build(z32, z32, z32, z8, n_terms=5, n_docs=0, n_articles=0)
+    st = ix.stats()
+    assert st["n_docs"] == 1 and st["avgdl"] == 0.0           # `or 1`, `or 0.0` (bm25_stats.py:10,13)
+    np.testing.assert_array_equal(st["df"], np.zeros(5, np.uint32))
+    np.testing.assert_allclose(st["idf"], np.log(2 * 1 + 2), rtol=1e-15)  # df = 0: ln(2N + 2)
+    out = ix.search([[0, 1]], k=5)
+    assert out["count"][0] == 0
+
+
+def test_range_errors(gpu_index_factory):
+    ix = gpu_index_factory()
+    one = np.ones(1, np.uint32)
+    m = np.array([se.meta(1, 4)], np.uint8)
+    with pytest.raises(se.Sebm25Error) as e:
+        ix.build(np.array([9], np.uint32), np.zeros(1, np.uint32), one, m, n_terms=5, n_docs=3)
+    assert e.value.code == 2
+    with pytest.raises(se.Sebm25Error) as e:
+        ix.build(np.zeros(1, np.uint32), np.array([3], np.uint32), one, m, n_terms=5, n_docs=3)
+    assert e.value.code == 2
+    with pytest.raises(se.Sebm25Error) as e:
+        ix.build(np.zeros(1, np.uint32), np.zeros(1, np.uint32), one, np.array([3], np.uint8), n_terms=5, n_docs=3)
+    assert e.value.code == 2
+    with pytest.raises(se.Sebm25Error) as e:
+        ix.stats()
+    assert e.value.code == 5
+
+
+def test_device_resident_inputs(gpu_index_factory):
+    import torch
+
+    c = small_corpus(n_docs=600, n_terms=4000, n_articles=20)
+    orc = oracle_index(c)
+    dev = {k: torch.from_numpy(c[k].view(np.int32) if c[k].dtype == np.uint32 else c[k]).cuda()
+           for k in ("term_id", "unit_id", "tf", "meta", "word_count")}
+    ix = gpu_index_factory()
+    ix.build(dev["term_id"], dev["unit_id"], dev["tf"], dev["meta"], c["n_terms"], c["n_docs"], c["n_articles"],
+             dev["word_count"])
+    assert_build_matches(ix, orc)
+
+
+def test_gpu_generator_matches_cpu_generator(gpu_index_factory):
+    import torch
+
+    ix = gpu_index_factory()
+    spec = se.make_spec(n_terms=5000, n_docs=700, n_articles=90)
+    n = ix.gen_corpus_rows(spec)
+    ospec = O.make_spec(n_terms=5000, n_docs=700, n_articles=90)
+    c = O.gen_corpus(ospec)
+    assert n == len(c["term_id"])
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    u = torch.empty_like(t)
+    f = torch.empty_like(t)
+    m = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wc = torch.empty(700, dtype=torch.int32, device="cuda")
+    assert ix.gen_corpus(spec, t, u, f, m, wc) == n
+    np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), c["term_id"])
+    np.testing.assert_array_equal(u.cpu().numpy().view(np.uint32), c["unit_id"])
+    np.testing.assert_array_equal(f.cpu().numpy().view(np.uint32), c["tf"])
+    np.testing.assert_array_equal(m.cpu().numpy(), c["meta"])
+    np.testing.assert_array_equal(wc.cpu().numpy().view(np.uint32), c["word_count"])
+    np.testing.assert_array_equal(se.zipf_cdf(5000), O.zipf_cdf(5000))
+    np.testing.assert_array_equal(se.gen_queries(20260228, 5000, 50, 3, 100),
+                                  O.gen_queries(20260228, 5000, O.zipf_cdf(5000), 100, 50, 3))

@@ -1,0 +1,158 @@
+"""GPU parity: batched scoring + top-k through the C ABI against the CPU oracle."""
+import numpy as np
+import pytest
+
+import search_engine_amd as se
+from oracle import oracle as O
+
+from helpers import assert_topk_valid, gpu_build, oracle_index, small_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _queries(n_terms, n_queries, tpq=3, min_rank=1, seed=20260228):
+    return O.gen_queries(seed, n_terms, O.zipf_cdf(n_terms), min_rank, n_queries, tpq)
+
+
+@pytest.fixture(scope="module")
+def built(gpu_index_factory):
+    c = small_corpus(n_docs=3000, n_terms=6000, n_articles=400)
+    orc = oracle_index(c)
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    ix.set_idf(orc.idf)  # same idf bits on both sides: scores from the float postings are then bit-exact
+    return c, orc, ix
+
+
+@pytest.mark.parametrize("k", [1, 10, 64, 210, 2000])
+@pytest.mark.parametrize("source", [se.SRC_WEB, se.SRC_NEWS])
+def test_topk_matches_reference_formula(built, k, source):
+    c, orc, ix = built
+    qs = _queries(c["n_terms"], 40, 3, min_rank=1 if k >= 64 else 20)
+    out = ix.search(qs, k, source=source)
+    for qi, q in enumerate(qs):
+        n = int(out["count"][qi])
+        ru, rs, rm = orc.search(q, max(k, 4096), source=source, level="rows")  # the SQL formula, row by row
+        assert_topk_valid(out["unit"][qi, :n], out["score"][qi, :n], out["matched"][qi, :n], ru, rs, rm, k)
+        assert (out["unit"][qi, n:] == se.PAD_UNIT).all()
+
+
+@pytest.mark.parametrize("k", [10, 210])
+def test_topk_bit_exact_against_posting_level_oracle(built, k):
+    c, orc, ix = built
+    qs = _queries(c["n_terms"], 60, 3, min_rank=5)
+    out = ix.search(qs, k)
+    for qi, q in enumerate(qs):
+        ru, rs, rm = orc.search(q, k, level="csr")
+        n = int(out["count"][qi])
+        assert n == len(ru)
+        np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+        np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+        np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+
+
+def test_query_edge_cases(built):
+    c, orc, ix = built
+    V = c["n_terms"]
+    qs = [[], [V + 5], [3, 3, 3], [7, V + 1, 7, 11], list(range(40, 70))]
+    out = ix.search(qs, 10)
+    assert out["count"][0] == 0 and out["count"][1] == 0
+    for qi in (2, 3, 4):
+        ru, rs, rm = orc.search(np.array(qs[qi], np.uint32), 10, level="csr")
+        n = int(out["count"][qi])
+        np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+        np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+        np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+    assert out["matched"][2, 0] == 1  # a repeated term counts once
+    with pytest.raises(se.Sebm25Error):
+        ix.search([list(range(0, 80))], 10)  # more than 64 distinct matching terms
+    with pytest.raises(se.Sebm25Error):
+        ix.search([[1]], 0)
+    with pytest.raises(se.Sebm25Error):
+        ix.search([[1]], 5000)
+
+
+def test_missing_idf_is_one_and_url_rank_breaks_ties(built):
+    c, orc, ix = built
+    V = c["n_terms"]
+    present = np.ones(V, np.uint8)
+    present[::3] = 0
+    idf = orc.idf.copy()
+    try:
+        ix.set_idf(idf, present)
+        orc.set_idf(idf, present)
+        rng = np.random.default_rng(11)
+        rank = rng.permutation(c["n_docs"]).astype(np.uint32)
+        ix.set_url_rank(se.SRC_WEB, rank)
+        qs = _queries(V, 30, 2, min_rank=300)  # rare terms with tf 1: many exact score ties
+        out = ix.search(qs, 20)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, 20, url_rank=rank, level="csr")
+            n = int(out["count"][qi])
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+    finally:
+        ix.set_url_rank(se.SRC_WEB, None)
+        ix.set_idf(orc.idf)
+        orc.set_idf(orc.idf)
+
+
+def test_sliced_long_queries_equal_unsliced(gpu_index_factory):
+    # head terms over a larger corpus force the unit-range split + merge path
+    c = small_corpus(n_docs=40_000, n_terms=3000, body_min=20, body_max=60, title_len=2, desc_len=4)
+    orc = oracle_index(c)
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    ix.set_idf(orc.idf)
+    qs = np.array([[0, 1, 2], [3, 9, 700], [5, 6, 2999]], np.uint32)
+    for k in (10, 300):
+        out = ix.search(qs, k)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, level="csr")
+            n = int(out["count"][qi])
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+
+
+def test_sharded_build_and_merge_equals_unsharded(gpu_index_factory):
+    n_docs, n_art, V = 2400, 300, 5000
+    full = small_corpus(n_docs=n_docs, n_terms=V, n_articles=n_art)
+    orc = oracle_index(full)
+    G = 3
+    shards, dfs, tots = [], [], []
+    for g in range(G):
+        d0, d1 = n_docs * g // G, n_docs * (g + 1) // G
+        a0, a1 = n_art * g // G, n_art * (g + 1) // G
+        spec = O.make_spec(n_terms=V, n_docs=d1 - d0, n_articles=a1 - a0, doc_begin=d0, article_begin=a0)
+        c = O.gen_corpus(spec)
+        ix = gpu_index_factory()
+        gpu_build(ix, c, local=True)
+        ix.set_unit_base(d0, a0)
+        df, t = ix.local_stats()
+        shards.append(ix)
+        dfs.append(df.astype(np.uint64))
+        tots.append(t)
+    df_global = sum(dfs).astype(np.uint32)  # what the all-reduce computes
+    tg = se.DocTotals(sum(t.n_done for t in tots), sum(t.n_wc for t in tots), sum(t.sum_wc for t in tots),
+                      sum(t.n_postings for t in tots))
+    np.testing.assert_array_equal(df_global, orc.df)
+    assert tg.n_postings == orc.totals.n_postings
+    for ix in shards:
+        ix.finalize(df_global, tg)
+        st = ix.stats()
+        np.testing.assert_array_equal(st["df"], orc.df)
+        assert st["n_docs"] == orc.n_docs_stat and st["avgdl"] == orc.avgdl
+        ix.set_idf(orc.idf)
+    qs = O.gen_queries(5, V, O.zipf_cdf(V), 10, 25, 3)
+    for source in (se.SRC_WEB, se.SRC_NEWS):
+        k = 15
+        parts = [ix.search(qs, k, source=source, want_tie=True) for ix in shards]
+        cat = {key: np.ascontiguousarray(np.stack([p[key] for p in parts])) for key in ("unit", "score", "matched", "tie", "count")}
+        merged = shards[0].merge_topk(G, len(qs), k, cat["unit"], cat["score"], cat["matched"], cat["tie"], cat["count"])
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, source=source, level="csr")
+            n = int(merged["count"][qi])
+            np.testing.assert_array_equal(merged["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(merged["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(merged["matched"][qi, :n], rm)
