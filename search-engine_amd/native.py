@@ -84,6 +84,14 @@ def lib():
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C search-engine_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  A process must run on ONE HIP
+    # runtime: if this library pulled in the system runtime first, torch's later initialisation
+    # finds no GPU.  Importing torch first makes the dynamic loader resolve this library's
+    # libamdhip64.so.7 dependency to the copy torch has already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     L.sebm25_create.argtypes = [i32, C.POINTER(vp)]
