@@ -2,6 +2,7 @@
 // the build / search pipelines as sequences of kernel launches, and result copies.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -15,7 +16,7 @@ thread_local std::string g_thread_err;
 constexpr uint32_t MAX_K = 2048;
 constexpr uint32_t MAX_QUERY_TERMS = 64;
 constexpr uint32_t SORT_MAX_CHUNKS = 512;
-constexpr uint32_t RED_MAX_CHUNKS = 1024;
+constexpr uint32_t RED_MAX_CHUNKS = 4096;  // wavefronts
 }  // namespace
 
 struct sebm25_index {
@@ -29,6 +30,7 @@ struct sebm25_index {
     uint32_t V = 0, n_docs = 0, n_articles = 0;
     RowFmt fmt{1, 1, 59};
     uint32_t n_pass = 0;
+    int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
     uint64_t P = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
     sebm25_doc_totals local_totals{}, used_totals{};
@@ -97,12 +99,14 @@ int stage_in(sebm25_index* ix, const T* src, size_t n, DevBuf& buf, const T** ou
         *out = nullptr;
         return SEBM25_OK;
     }
-    if (is_device_ptr(src)) {
+    // kernels read rows with 16-byte vector loads: a device array that is not 16-byte aligned
+    // (a view into a larger allocation) is copied once into aligned staging memory
+    if (is_device_ptr(src) && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
         *out = src;
         return SEBM25_OK;
     }
     HIP_TRY(ix, buf.ensure(n * sizeof(T)));
-    HIP_TRY(ix, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyDefault, ix->stream));
     *out = buf.as<T>();
     return SEBM25_OK;
 }
@@ -255,7 +259,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         const bool unit_major = (in->flags & SEBM25_ROWS_UNIT_MAJOR) != 0;
         const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
         const int key_bits = 64 - key_lo;
-        const int n_pass = (key_bits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+        const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
         ix->n_pass = (uint32_t)n_pass;
         uint32_t G = (uint32_t)std::min<uint64_t>((R + SORT_TILE - 1) / SORT_TILE, SORT_MAX_CHUNKS);
         uint64_t chunk_rows = (R + G - 1) / G;
@@ -303,20 +307,25 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ix->post_unit = reinterpret_cast<uint32_t*>(other);
         ix->post_w = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(other) + Rcap);
 
-        // ---- segmented reduction into postings
-        uint32_t G2 = (uint32_t)std::min<uint64_t>((R + RED_TILE - 1) / RED_TILE, RED_MAX_CHUNKS);
-        uint64_t chunk2 = (R + G2 - 1) / G2;
-        chunk2 = (chunk2 + RED_TILE - 1) / RED_TILE * RED_TILE;
-        G2 = (uint32_t)((R + chunk2 - 1) / chunk2);
-        HIP_TRY(ix, ix->chunk_counts.ensure((size_t)G2 * 8));
+        // ---- segmented reduction into postings: one contiguous range of rows per wavefront
+        uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
+        chunk2 = (chunk2 + RED_BATCH - 1) / RED_BATCH * RED_BATCH;
+        const uint32_t n_chunks = (uint32_t)((R + chunk2 - 1) / chunk2);
+        HIP_TRY(ix, ix->chunk_counts.ensure((size_t)2 * (n_chunks + 1) * 4));
+        uint32_t* cnt_kept = ix->chunk_counts.as<uint32_t>();
+        uint32_t* cnt_wh = cnt_kept + (n_chunks + 1);
+        HIP_TRY(ix, hipMemsetAsync(cnt_kept, 0, (size_t)2 * (n_chunks + 1) * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
         phase_begin(ix, "reduce_count");
-        launch_reduce_count(sorted, R, chunk2, G2, fmt, flags_dev, ix->chunk_counts.as<uint64_t>(), ix->stream);
+        launch_reduce_count(sorted, R, chunk2, n_chunks, fmt, flags_dev, cnt_kept, cnt_wh, ix->stream);
+        phase_end(ix);
+        phase_begin(ix, "reduce_scan");
+        launch_exclusive_scan_u32(cnt_kept, n_chunks + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
+        launch_exclusive_scan_u32(cnt_wh, n_chunks + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
         phase_end(ix);
         phase_begin(ix, "reduce_emit");
-        launch_reduce_emit(sorted, R, chunk2, G2, fmt, flags_dev, ix->chunk_counts.as<uint64_t>(), V, ix->post_unit,
-                           ix->post_w, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal,
-                           ix->stream);
+        launch_reduce_emit(sorted, R, chunk2, n_chunks, fmt, flags_dev, cnt_kept, cnt_wh, V, ix->post_unit, ix->post_w,
+                           row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal, ix->stream);
         phase_end(ix);
         phase_begin(ix, "term_stats");
         launch_term_stats(V, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(),
@@ -367,6 +376,7 @@ int sebm25_create(int device, sebm25_index** out) {
     sebm25_index* ix = new (std::nothrow) sebm25_index();
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
+    if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     *out = ix;
     return SEBM25_OK;
 }

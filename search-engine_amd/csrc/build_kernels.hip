@@ -4,9 +4,9 @@
 // the reference (app/batch/bm25_stats.py:16-27) and the document aggregates at :9-13.
 //
 // Every kernel here is bandwidth-bound integer work: rows stream through in coalesced
-// 64-lane accesses, digit ranking uses wave ballots, and each workgroup owns a contiguous
-// chunk of rows so that the runs it appends to a digit bin are adjacent in memory and merge
-// in its XCD's L2 before they reach HBM.
+// 64-lane accesses with all loads of a tile issued before the first use, digit ranking uses
+// wave ballots, and each workgroup owns a contiguous chunk of rows so that the runs it appends
+// to a digit bin are adjacent in memory and merge in its XCD's L2 before they reach HBM.
 #include "common.hpp"
 
 namespace sebm25 {
@@ -27,42 +27,97 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int bits, bool valid
 
 __device__ __forceinline__ uint32_t field_code(uint32_t field) { return field == 1u ? 1u : field == 2u ? 2u : 0u; }
 
-// MODE 0: raw rows, only term_id is read (digit inside the term bits)
-// MODE 1: raw rows, key packed from term/unit/meta
-// MODE 2: packed rows
-template <int MODE>
-__device__ __forceinline__ uint64_t load_key(const RawRows& raw, const uint64_t* packed, uint64_t i, const RowFmt& f) {
-    if (MODE == 0) return (uint64_t)raw.term[i] << f.term_shift();
-    if (MODE == 1) {
-        const uint32_t m = raw.meta[i];
-        return f.pack(raw.term[i], ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u, raw.unit[i], 0u, 0ull);
-    }
-    return packed[i];
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
 }
 
 // ------------------------------------------------------------------ histogram (upsweep) ---
 // Workgroup g counts the digits of its chunk of rows; counts are stored bin-major
 // (chunk_hist[bin * G + g]) so that one flat exclusive scan yields every chunk's write base.
+// MODE 0: raw rows, only term_id is read (the digit lies inside the term bits)
+// MODE 1: raw rows, digit taken from the key packed from term / source / unit
+// MODE 2: packed rows
+constexpr int HIST_THREADS = 1024;
+constexpr int HIST_UNROLL = 4;
+
+// One count per lane.  Sorted or skewed input often gives a whole wave the same digit; then
+// one lane adds the wave's population instead of 64 lanes hitting one LDS word.
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid) {
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return;
+    const int first = __ffsll((unsigned long long)vm) - 1;
+    const uint32_t d0 = __shfl(d, first);
+    if (__all(!valid || d == d0)) {
+        if ((int)lane_id() == first) atomicAdd(&hist[d0], (uint32_t)__popcll(vm));
+    } else if (valid) {
+        atomicAdd(&hist[d], 1u);
+    }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(RawRows raw, const uint64_t* packed, uint64_t R,
+__global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const uint64_t* packed, uint64_t R,
                                                             uint64_t chunk_rows, uint32_t G, int shift, int bits,
                                                             RowFmt fmt, uint32_t* chunk_hist) {
     __shared__ uint32_t hist[SORT_MAX_BINS];
     const uint32_t nb = 1u << bits, mask = nb - 1u;
-    for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) hist[d] = 0;
+    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) hist[d] = 0;
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
-    for (uint64_t i0 = begin; i0 < end; i0 += SORT_THREADS) {
-        const uint64_t i = i0 + threadIdx.x;
-        const bool valid = i < end;
-        uint32_t d = 0;
-        if (valid) d = (uint32_t)(load_key<MODE>(raw, packed, i, fmt) >> shift) & mask;
-        const uint64_t peers = match_digit(d, bits, valid);
-        if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
+    const uint64_t n = end - begin;
+    if (MODE == 0) {
+        // chunk starts are multiples of the tile size, so 16-byte vector loads stay aligned
+        const int sh = shift - fmt.term_shift();
+        const uint4* p = reinterpret_cast<const uint4*>(raw.term + begin);
+        const uint64_t nvec = n / 4;
+        for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)HIST_THREADS * HIST_UNROLL) {
+            uint4 x[HIST_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HIST_UNROLL; ++u) {
+                const uint64_t v = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x;
+                x[u] = v < nvec ? p[v] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < HIST_UNROLL; ++u) {
+                const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
+                hist_add(hist, (x[u].x >> sh) & mask, ok);
+                hist_add(hist, (x[u].y >> sh) & mask, ok);
+                hist_add(hist, (x[u].z >> sh) & mask, ok);
+                hist_add(hist, (x[u].w >> sh) & mask, ok);
+            }
+        }
+        for (uint64_t i = begin + nvec * 4 + threadIdx.x; i < end; i += HIST_THREADS)
+            atomicAdd(&hist[(raw.term[i] >> sh) & mask], 1u);
+    } else if (MODE == 2) {
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(packed + begin);
+        const uint64_t nvec = n / 2;
+        for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)HIST_THREADS * HIST_UNROLL) {
+            ulonglong2 x[HIST_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HIST_UNROLL; ++u) {
+                const uint64_t v = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x;
+                x[u] = v < nvec ? p[v] : make_ulonglong2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < HIST_UNROLL; ++u) {
+                const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
+                hist_add(hist, (uint32_t)(x[u].x >> shift) & mask, ok);
+                hist_add(hist, (uint32_t)(x[u].y >> shift) & mask, ok);
+            }
+        }
+        for (uint64_t i = begin + nvec * 2 + threadIdx.x; i < end; i += HIST_THREADS)
+            atomicAdd(&hist[(uint32_t)(packed[i] >> shift) & mask], 1u);
+    } else {
+        for (uint64_t i = begin + threadIdx.x; i < end; i += HIST_THREADS) {
+            const uint32_t m = raw.meta[i];
+            const uint64_t key = fmt.pack(raw.term[i], ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u, raw.unit[i], 0u, 0ull);
+            atomicAdd(&hist[(uint32_t)(key >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) chunk_hist[(size_t)d * G + blockIdx.x] = hist[d];
+    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) chunk_hist[(size_t)d * G + blockIdx.x] = hist[d];
 }
 
 // ------------------------------------------------------------------ scatter (downsweep) ---
@@ -87,8 +142,11 @@ __device__ __forceinline__ void block_exclusive_scan_1024(uint32_t* v, uint32_t 
     __syncthreads();
 }
 
+constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-length counters
+
+// MODE 1: raw rows in (validated, packed, body lengths accumulated); MODE 2: packed rows in.
 template <int MODE>
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
+__global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                uint64_t R, uint64_t chunk_rows, uint32_t G, int shift,
                                                                int bits, BuildCtx ctx, const uint32_t* chunk_off) {
     __shared__ uint32_t whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then per-wave offsets
@@ -96,6 +154,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, cons
     __shared__ uint32_t tile_start[SORT_MAX_BINS];         // first local slot of each digit
     __shared__ uint32_t bin_base[SORT_MAX_BINS];           // next global slot of each digit for this chunk
     __shared__ uint32_t wave_tot[SORT_WAVES];
+    __shared__ uint32_t dl_s[DL_SPAN];                     // body length per doc of this tile
 
     const RowFmt fmt = ctx.fmt;
     const uint32_t nb = 1u << bits, mask = nb - 1u;
@@ -103,73 +162,108 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, cons
     const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
     for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) bin_base[d] = chunk_off[(size_t)d * G + blockIdx.x];
+    for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
+    if (MODE != 2) dl_s[threadIdx.x] = 0;
+    __syncthreads();
 
+    // All loads of a tile are issued before the first use (the other workgroup on the CU covers
+    // their latency; loading a tile ahead was measured and bought nothing).
+    uint64_t row[SORT_ITEMS];
+    uint32_t term[SORT_ITEMS], unit[SORT_ITEMS], tfv[SORT_ITEMS], m[SORT_ITEMS];
+    uint64_t carry_in = 0;   // (source, unit) of the row before this wave's first row
+    uint32_t u_first = 0;    // first doc of the tile
+    bool tile_web = false;
+    auto load_tile = [&](uint64_t t0) {
+        const uint64_t w0 = t0 + (uint64_t)wave * 64u * SORT_ITEMS;
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) {
+                const uint64_t i = w0 + (uint64_t)j * 64u + lane;
+                row[j] = i < end ? packed[i] : ~0ull;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) {
+                const uint64_t i = w0 + (uint64_t)j * 64u + lane;
+                const bool valid = i < end;
+                term[j] = valid ? raw.term[i] : 0u;
+                unit[j] = valid ? raw.unit[i] : 0u;
+                tfv[j] = valid ? raw.tf[i] : 0u;
+                m[j] = valid ? raw.meta[i] : (uint32_t)SEBM25_SRC_WEB;
+            }
+            carry_in = 0;
+            if (w0 > 0 && w0 < end) {
+                const uint32_t pm = raw.meta[w0 - 1];
+                carry_in = ((uint64_t)(((pm & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | raw.unit[w0 - 1];
+            }
+            if (t0 < end) {
+                u_first = raw.unit[t0];
+                tile_web = (raw.meta[t0] & 3u) == SEBM25_SRC_WEB;
+            }
+        }
+    };
     for (uint64_t tile0 = begin; tile0 < end; tile0 += SORT_TILE) {
-        for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
-        __syncthreads();
-
-        // ---- load + rank: wave w owns rows [tile0 + w*64*ITEMS, +64*ITEMS), 64 consecutive rows per round
-        uint64_t row[SORT_ITEMS];
-        uint32_t rk[SORT_ITEMS];
+        load_tile(tile0);
+        // wave w owns rows [tile0 + w*64*ITEMS, +64*ITEMS), 64 consecutive rows per round
         const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;
+        const uint32_t tile_u_first = u_first;
+        if (MODE != 2) {
+            uint64_t carry = carry_in;
+            const bool t_web = tile_web;
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) {
+                const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
+                const bool valid = i < end;
+                const uint32_t st = m[j] & 3u, field = m[j] >> 2;
+                const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
+                uint64_t r = ~0ull;
+                if (valid) {
+                    const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
+                                     unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
+                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
+                    if (bad) {
+                        atomicOr(ctx.err, DEV_ERR_RANGE);
+                        term[j] = min(term[j], ctx.n_terms - 1u);  // keep every later index in range
+                        unit[j] = 0;
+                        tfv[j] = 0;
+                    }
+                    r = fmt.pack(term[j], src, unit[j], field_code(field), tfv[j]);
+                }
+                row[j] = r;
+                // unit-major check: (source, unit) must not decrease from one row to the next
+                const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit[j]) : ~0ull;
+                uint64_t prev = __shfl_up(ukey, 1);
+                if (lane == 0) prev = carry;
+                carry = __shfl(ukey, 63);
+                if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
+                // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
+                // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
+                const uint32_t body = (valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
+                const uint64_t first_key = __shfl(ukey, 0);
+                const bool uniform = __all(ukey == first_key);
+                uint32_t add = body;
+                bool do_add = body != 0u;
+                if (uniform) {
+                    add = wave_sum_u32(body);
+                    do_add = lane == 0 && add != 0u;
+                }
+                if (do_add) {
+                    const uint32_t off = unit[j] - tile_u_first;
+                    if (t_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
+                        atomicAdd(&dl_s[off], add);
+                    else
+                        atomicAdd(&ctx.doc_len[unit[j]], add);
+                }
+            }
+        }
+
+        // ---- rank: position of each row among the rows of its digit held by this wave
+        uint32_t rk[SORT_ITEMS];
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
             const bool valid = i < end;
-            uint64_t r = ~0ull;
-            if (MODE == 2) {
-                if (valid) r = packed[i];
-            } else {
-                uint32_t term = 0, unit = 0, tfv = 0, m = SEBM25_SRC_WEB;
-                if (valid) {
-                    term = raw.term[i];
-                    unit = raw.unit[i];
-                    tfv = raw.tf[i];
-                    m = raw.meta[i];
-                }
-                const uint32_t st = m & 3u, field = m >> 2;
-                const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
-                if (valid) {
-                    const bool bad = term >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
-                                     unit >= (src ? ctx.n_articles : ctx.n_docs) ||
-                                     (fmt.tf_bits < 32 && (tfv >> fmt.tf_bits) != 0u);
-                    if (bad) {
-                        atomicOr(ctx.err, DEV_ERR_RANGE);
-                        term = min(term, ctx.n_terms - 1u);  // keep every later index in range
-                        unit = 0;
-                        tfv = 0;
-                    }
-                    r = fmt.pack(term, src, unit, field_code(field), tfv);
-                }
-                // unit-major check and per-document body length (both on runs of equal (src, unit))
-                const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit) : ~0ull;
-                uint64_t prev = __shfl_up(ukey, 1);
-                if (lane == 0) {
-                    prev = 0;
-                    if (valid && i > 0) {
-                        const uint32_t pm = raw.meta[i - 1];
-                        prev = ((uint64_t)(((pm & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | raw.unit[i - 1];
-                    }
-                }
-                if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
-                const bool head = (lane == 0) || (ukey != prev);
-                const uint64_t heads = __ballot(head);
-                uint32_t inc = (valid && src == 0u && field == SEBM25_FIELD_BODY && unit < ctx.n_docs) ? tfv : 0u;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t x = __shfl_up(inc, off);
-                    if ((int)lane >= off) inc += x;
-                }
-                const uint32_t head_lane = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane)));
-                const uint32_t before = __shfl(inc, (int)((head_lane + 63u) & 63u));
-                const bool tail = (lane == 63u) || ((heads >> (lane + 1u)) & 1ull);
-                if (tail) {
-                    const uint32_t sum = inc - (head_lane ? before : 0u);
-                    if (sum) atomicAdd(&ctx.doc_len[unit], sum);
-                }
-            }
-            row[j] = r;
-            const uint32_t d = (uint32_t)(r >> shift) & mask;
+            const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
             const uint64_t peers = match_digit(d, bits, valid);
             const int leader = __ffsll((unsigned long long)peers) - 1;
             uint32_t old = 0;
@@ -183,7 +277,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, cons
         }
         __syncthreads();
 
-        // ---- per digit: exclusive offsets over the waves, tile count
+        // ---- per digit: exclusive offsets over the waves, tile count; flush body lengths
         for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) {
             uint32_t run = 0;
 #pragma unroll
@@ -193,6 +287,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, cons
                 run += c;
             }
             tile_start[d] = run;
+        }
+        if (MODE != 2) {
+            const uint32_t v = dl_s[threadIdx.x];
+            if (v) {
+                atomicAdd(&ctx.doc_len[tile_u_first + threadIdx.x], v);
+                dl_s[threadIdx.x] = 0;
+            }
         }
         __syncthreads();
         block_exclusive_scan_1024(tile_start, nb, wave_tot);
@@ -215,18 +316,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(RawRows raw, cons
             const uint32_t d = (uint32_t)(r >> shift) & mask;
             dst[(uint64_t)bin_base[d] + (p - tile_start[d])] = r;
         }
+        for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) {
             const uint32_t nxt = (d + 1 < nb) ? tile_start[d + 1] : n_tile;
             bin_base[d] += nxt - tile_start[d];
         }
-        // the barrier after zeroing whist at the top of the next tile orders these updates
+        // bin_base is next read after the following tile's barriers; tile_start is next written
+        // after the barrier that ends its rank phase
     }
 }
 
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
                       int shift, int bits, const BuildCtx& ctx, uint32_t* chunk_hist, hipStream_t st) {
-    dim3 grid(G), block(SORT_THREADS);
+    dim3 grid(G), block(HIST_THREADS);
     if (mode == 0)
         hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, chunk_hist);
     else if (mode == 1)
@@ -273,15 +376,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const uint32_t* data
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-// one workgroup: exclusive scan of the block sums in place (any count)
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* sums, size_t nblocks) {
+// one workgroup: exclusive scan of `n` words in place (any count)
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t* sums, size_t n) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (size_t base = 0; base < nblocks; base += 1024) {
+    for (size_t base = 0; base < n; base += 1024) {
         const size_t i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? sums[i] : 0u;
+        const uint32_t v = i < n ? sums[i] : 0u;
         uint32_t inc = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -293,7 +396,7 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* sums, size_t
         uint32_t wbase = 0;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += wtot[w];
         const uint32_t carry = carry_s;
-        if (i < nblocks) sums[i] = carry + wbase + inc - v;
+        if (i < n) sums[i] = carry + wbase + inc - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wbase + inc;
         __syncthreads();
@@ -332,24 +435,31 @@ size_t scan_tmp_words(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
 
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st) {
     if (n == 0) return;
+    if (n <= 8192) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, data, n);
+        return;
+    }
     const size_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st, data, n, tmp);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, st, tmp, nblocks);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, tmp, nblocks);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st, data, n, tmp);
 }
 
 // ------------------------------------------------------------------ segmented reduction ---
-// Sorted rows -> one posting per (term, source, unit).  flags per row:
+// Sorted rows -> one posting per (term, source, unit).  Each wavefront streams its own
+// contiguous range of rows (no workgroup barriers): 64 consecutive rows per load, neighbours
+// compared through lane shuffles, output slots from ballot prefix counts, so posting stores
+// are coalesced.  Flags per row:
 //   head    : first row of its (term, source, unit) run
 //   kept    : head of a news unit, or of a web doc whose status is 'done' (search_service.py:32)
 //   webhead : head of a web doc of any status -> counts toward df (bm25_stats.py:20)
 struct RowFlags {
     bool head, kept, webhead;
 };
-__device__ __forceinline__ RowFlags row_flags(uint64_t r, uint64_t prev, bool first, const RowFmt& f,
+__device__ __forceinline__ RowFlags row_flags(uint64_t r, uint64_t prev, bool first, bool valid, const RowFmt& f,
                                               const uint8_t* doc_flags) {
     RowFlags x;
-    x.head = first || f.key(r) != f.key(prev);
+    x.head = valid && (first || f.key(r) != f.key(prev));
     const bool news = f.src(r) != 0u;
     x.webhead = x.head && !news;
     x.kept = x.head && (news || !doc_flags || (doc_flags[f.unit(r)] & SEBM25_DOC_DONE));
@@ -357,154 +467,157 @@ __device__ __forceinline__ RowFlags row_flags(uint64_t r, uint64_t prev, bool fi
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows,
-                                                              RowFmt fmt, const uint8_t* doc_flags,
-                                                              uint64_t* chunk_counts) {
-    __shared__ uint32_t sh[RED_THREADS / 64];
-    const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
+                                                              uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
+                                                              uint32_t* cnt_kept, uint32_t* cnt_wh) {
+    const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint32_t lane = lane_id();
+    const uint64_t begin = (uint64_t)c * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
+    uint64_t carry = begin ? rows[begin - 1] : 0ull;
     uint32_t kept = 0, wh = 0;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += RED_THREADS) {
-        const uint64_t r = rows[i];
-        const uint64_t prev = i ? rows[i - 1] : 0ull;
-        const RowFlags fl = row_flags(r, prev, i == 0, fmt, doc_flags);
-        kept += fl.kept;
-        wh += fl.webhead;
+    for (uint64_t b0 = begin; b0 < end; b0 += 64u * RED_ROUNDS) {
+        uint64_t r[RED_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) {
+            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
+            r[j] = i < end ? rows[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) {
+            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
+            uint64_t prev = __shfl_up(r[j], 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(r[j], 63);
+            const RowFlags fl = row_flags(r[j], prev, i == 0, i < end, fmt, doc_flags);
+            kept += (uint32_t)__popcll(__ballot(fl.kept));
+            wh += (uint32_t)__popcll(__ballot(fl.webhead));
+        }
     }
-    const uint32_t tk = block_reduce_u32(kept, sh);
-    const uint32_t tw = block_reduce_u32(wh, sh);
-    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = (uint64_t)tk | ((uint64_t)tw << 32);
+    if (lane == 0) {
+        cnt_kept[c] = kept;
+        cnt_wh[c] = wh;
+    }
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows,
-                                                             uint32_t G, RowFmt fmt, const uint8_t* doc_flags,
-                                                             const uint64_t* chunk_counts, uint32_t n_terms,
-                                                             uint32_t* post_unit, float* post_w, uint32_t* row_ptr,
-                                                             uint32_t* news_ptr, uint32_t* wh_ptr, uint32_t* rs_ptr,
-                                                             uint64_t* totals_out) {
-    __shared__ uint64_t sh64[RED_THREADS / 64];
-    __shared__ uint64_t run_s;
-    const uint32_t t = threadIdx.x;
-    // exclusive prefix of the chunk counts: low word kept postings, high word web heads
-    uint64_t part = 0;
-    for (uint32_t g = t; g < blockIdx.x; g += RED_THREADS) part += chunk_counts[g];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-    if (lane_id() == 0) sh64[t >> 6] = part;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t s = 0;
-        for (int w = 0; w < RED_THREADS / 64; ++w) s += sh64[w];
-        run_s = s;
-    }
-    __syncthreads();
-
-    const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
+                                                             uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
+                                                             const uint32_t* off_kept, const uint32_t* off_wh,
+                                                             uint32_t n_terms, uint32_t* post_unit, float* post_w,
+                                                             uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
+                                                             uint32_t* rs_ptr, uint64_t* totals_out) {
+    const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const uint64_t begin = (uint64_t)c * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
-    for (uint64_t tile0 = begin; tile0 < end; tile0 += RED_TILE) {
-        const uint64_t i0 = tile0 + (uint64_t)t * RED_ITEMS;
-        uint64_t r[RED_ITEMS];
-        uint64_t prev = (i0 > 0 && i0 < end) ? rows[i0 - 1] : 0ull;
-        const uint64_t prev0 = prev;
-        uint64_t cnt = 0;
-        uint32_t headbits = 0, keptbits = 0, whbits = 0;
+    uint64_t carry = begin ? rows[begin - 1] : 0ull;
+    uint32_t base_k = off_kept[c], base_w = off_wh[c];
+    // rows past this wave's range are still loaded (they end runs that start inside it); the
+    // next batch is loaded before the current one is processed
+    uint64_t r[RED_ROUNDS], rn[RED_ROUNDS];
+    uint64_t after = 0, after_n = 0;
 #pragma unroll
-        for (int j = 0; j < RED_ITEMS; ++j) {
-            const uint64_t i = i0 + j;
-            r[j] = 0;
-            if (i < end) {
-                r[j] = rows[i];
-                const RowFlags fl = row_flags(r[j], prev, i == 0, fmt, doc_flags);
-                headbits |= (uint32_t)fl.head << j;
-                keptbits |= (uint32_t)fl.kept << j;
-                whbits |= (uint32_t)fl.webhead << j;
-                cnt += (uint64_t)fl.kept | ((uint64_t)fl.webhead << 32);
-                prev = r[j];
+    for (int j = 0; j < RED_ROUNDS; ++j) {
+        const uint64_t i = begin + (uint64_t)j * 64u + lane;
+        r[j] = i < R ? rows[i] : 0ull;
+    }
+    after = begin + RED_BATCH < R ? rows[begin + RED_BATCH] : 0ull;
+    for (uint64_t b0 = begin; b0 < end; b0 += RED_BATCH) {
+        const uint64_t nb0 = b0 + RED_BATCH;
+        if (nb0 < end) {
+#pragma unroll
+            for (int j = 0; j < RED_ROUNDS; ++j) {
+                const uint64_t i = nb0 + (uint64_t)j * 64u + lane;
+                rn[j] = i < R ? rows[i] : 0ull;
             }
+            after_n = nb0 + RED_BATCH < R ? rows[nb0 + RED_BATCH] : 0ull;
         }
-        // block exclusive scan of the packed counts
-        uint64_t inc = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t x = __shfl_up(inc, off);
-            if ((int)lane_id() >= off) inc += x;
-        }
-        if (lane_id() == 63) sh64[t >> 6] = inc;
-        __syncthreads();
-        uint64_t run = run_s + inc - cnt;
-        for (uint32_t w = 0; w < (t >> 6); ++w) run += sh64[w];
-        uint64_t tile_total = 0;
-        for (int w = 0; w < RED_THREADS / 64; ++w) tile_total += sh64[w];
-
-        prev = prev0;
-#pragma unroll
-        for (int j = 0; j < RED_ITEMS; ++j) {
-            const uint64_t i = i0 + j;
-            if (i < end) {
-                const uint32_t p = (uint32_t)run, wh = (uint32_t)(run >> 32);
-                const uint32_t term = fmt.term(r[j]);
-                if ((headbits >> j) & 1u) {
-                    const bool first = (i == 0);
-                    const uint32_t pterm = first ? 0u : fmt.term(prev);
-                    if (first || term != pterm) {
-                        // this row opens term `term`; terms without rows before it are empty
-                        for (uint32_t x = first ? 0u : pterm + 1u; x <= term; ++x) {
-                            row_ptr[x] = p;
-                            wh_ptr[x] = wh;
-                            rs_ptr[x] = (uint32_t)i;
-                        }
-                    }
-                    if (fmt.src(r[j]) && (first || term != pterm || fmt.src(prev) == 0u)) news_ptr[term] = p;
-                    if ((keptbits >> j) & 1u) {
-                        // weight: web sum_f tf_f * W[f] (search_service.py:19-27), news sum tf (:84-87);
-                        // double, mul then add in row order, rounded once to float
-                        const uint64_t key = fmt.key(r[j]);
-                        const bool news = fmt.src(r[j]) != 0u;
-                        double w = 0.0;
-                        uint64_t ii = i;
-                        uint64_t rr = r[j];
-                        while (true) {
-                            const double x = (double)fmt.tf(rr);
-                            const uint32_t fc = fmt.fc(rr);
-                            const double wf = news ? 1.0 : (fc == 1u ? 3.2 : fc == 2u ? 1.7 : 1.0);
-                            w = __dadd_rn(w, news ? x : __dmul_rn(x, wf));
-                            if (++ii >= R) break;
-                            rr = rows[ii];
-                            if (fmt.key(rr) != key) break;
-                        }
-                        post_unit[p] = fmt.unit(r[j]);
-                        post_w[p] = (float)w;
+        for (int j = 0; j < RED_ROUNDS; ++j) {
+            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
+            const bool valid = i < end;
+            uint64_t prev = __shfl_up(r[j], 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(r[j], 63);
+            uint64_t nxt = __shfl_down(r[j], 1);
+            const uint64_t nxt_round0 = (j + 1 < RED_ROUNDS) ? __shfl(r[(j + 1 < RED_ROUNDS) ? j + 1 : j], 0) : after;
+            if (lane == 63) nxt = nxt_round0;
+            const bool first = i == 0;
+            const RowFlags fl = row_flags(r[j], prev, first, valid, fmt, doc_flags);
+            const uint64_t km = __ballot(fl.kept), wm = __ballot(fl.webhead);
+            const uint32_t p = base_k + (uint32_t)__popcll(km & lt);
+            const uint32_t wh = base_w + (uint32_t)__popcll(wm & lt);
+            const uint32_t term = fmt.term(r[j]);
+            if (fl.head) {
+                const uint32_t pterm = first ? 0u : fmt.term(prev);
+                if (first || term != pterm) {
+                    // this row opens term `term`; terms without rows before it are empty
+                    for (uint32_t x = first ? 0u : pterm + 1u; x <= term; ++x) {
+                        row_ptr[x] = p;
+                        wh_ptr[x] = wh;
+                        rs_ptr[x] = (uint32_t)i;
                     }
                 }
-                run += (uint64_t)((keptbits >> j) & 1u) | ((uint64_t)((whbits >> j) & 1u) << 32);
-                if (i == R - 1) {
-                    for (uint32_t x = term + 1u; x <= n_terms; ++x) {
-                        row_ptr[x] = (uint32_t)run;
-                        wh_ptr[x] = (uint32_t)(run >> 32);
-                        rs_ptr[x] = (uint32_t)R;
-                    }
-                    totals_out[0] = run & 0xFFFFFFFFull;  // kept postings
-                    totals_out[1] = run >> 32;            // web heads (sum of df)
+                if (fmt.src(r[j]) && (first || term != pterm || fmt.src(prev) == 0u)) news_ptr[term] = p;
+            }
+            if (fl.kept) {
+                // weight: web sum_f tf_f * W[f] (search_service.py:19-27), news sum tf (:84-87);
+                // double, multiply then add in row order, rounded once to float
+                const uint64_t key = fmt.key(r[j]);
+                const bool news = fmt.src(r[j]) != 0u;
+                uint64_t rr = r[j];
+                uint64_t ii = i;
+                bool more = (i + 1 < R) && fmt.key(nxt) == key;
+                double w = 0.0;
+                while (true) {
+                    const double x = (double)fmt.tf(rr);
+                    const uint32_t fc = fmt.fc(rr);
+                    const double wf = fc == 1u ? 3.2 : fc == 2u ? 1.7 : 1.0;
+                    w = __dadd_rn(w, news ? x : __dmul_rn(x, wf));
+                    if (!more) break;
+                    rr = (ii == i) ? nxt : rows[ii + 1];
+                    ++ii;
+                    more = (ii + 1 < R) && fmt.key(rows[ii + 1]) == key;
                 }
-                prev = r[j];
+                post_unit[p] = fmt.unit(r[j]);
+                post_w[p] = (float)w;
+            }
+            base_k += (uint32_t)__popcll(km);
+            base_w += (uint32_t)__popcll(wm);
+            if (valid && i == R - 1) {
+                const uint32_t pk = p + (fl.kept ? 1u : 0u), pw = wh + (fl.webhead ? 1u : 0u);
+                for (uint32_t x = term + 1u; x <= n_terms; ++x) {
+                    row_ptr[x] = pk;
+                    wh_ptr[x] = pw;
+                    rs_ptr[x] = (uint32_t)R;
+                }
+                totals_out[0] = pk;  // kept postings
+                totals_out[1] = pw;  // web heads (sum of df)
             }
         }
-        __syncthreads();
-        if (t == 0) run_s += tile_total;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) r[j] = rn[j];
+        after = after_n;
     }
 }
 
-void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
-                         const uint8_t* doc_flags, uint64_t* chunk_counts, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_count, dim3(G), dim3(RED_THREADS), 0, st, rows, R, chunk_rows, fmt, doc_flags, chunk_counts);
+void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                         const uint8_t* doc_flags, uint32_t* cnt_kept, uint32_t* cnt_wh, hipStream_t st) {
+    const uint32_t wpb = RED_THREADS / 64;
+    hipLaunchKernelGGL(k_reduce_count, dim3((n_chunks + wpb - 1) / wpb), dim3(RED_THREADS), 0, st, rows, R, chunk_rows,
+                       n_chunks, fmt, doc_flags, cnt_kept, cnt_wh);
 }
 
-void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
-                        const uint8_t* doc_flags, const uint64_t* chunk_counts, uint32_t n_terms, uint32_t* post_unit,
-                        float* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr, uint32_t* rs_ptr,
-                        uint64_t* totals_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_emit, dim3(G), dim3(RED_THREADS), 0, st, rows, R, chunk_rows, G, fmt, doc_flags,
-                       chunk_counts, n_terms, post_unit, post_w, row_ptr, news_ptr, wh_ptr, rs_ptr, totals_out);
+void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                        const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
+                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
+                        uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st) {
+    const uint32_t wpb = RED_THREADS / 64;
+    hipLaunchKernelGGL(k_reduce_emit, dim3((n_chunks + wpb - 1) / wpb), dim3(RED_THREADS), 0, st, rows, R, chunk_rows,
+                       n_chunks, fmt, doc_flags, off_kept, off_wh, n_terms, post_unit, post_w, row_ptr, news_ptr, wh_ptr,
+                       rs_ptr, totals_out);
 }
 
 // ------------------------------------------------------------------ statistics ------------

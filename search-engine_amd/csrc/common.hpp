@@ -93,8 +93,8 @@ constexpr int SORT_MAX_BITS = 10;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
 
 constexpr int RED_THREADS = 256;
-constexpr int RED_ITEMS = 8;
-constexpr int RED_TILE = RED_THREADS * RED_ITEMS;
+constexpr int RED_ROUNDS = 8;                 // 64-row rounds a wave loads before it processes them
+constexpr int RED_BATCH = 64 * RED_ROUNDS;
 
 struct BuildCtx {
     RowFmt fmt;
@@ -116,12 +116,12 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
 
-void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
-                         const uint8_t* doc_flags, uint64_t* chunk_counts, hipStream_t st);
-void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t G, RowFmt fmt,
-                        const uint8_t* doc_flags, const uint64_t* chunk_counts, uint32_t n_terms,
-                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
-                        uint32_t* wh_ptr, uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st);
+void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                         const uint8_t* doc_flags, uint32_t* cnt_kept, uint32_t* cnt_wh, hipStream_t st);
+void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                        const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
+                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
+                        uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st);
 void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
                        const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows, hipStream_t st);
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
