@@ -31,6 +31,7 @@ struct sebm25_index {
     RowFmt fmt{1, 1, 59};
     uint32_t n_pass = 0;
     int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
+    int score_window = 1024;        // unit ids per scoring window (tuning knob: SEBM25_SCORE_WINDOW = 1024 | 2048)
     uint64_t P = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
     sebm25_doc_totals local_totals{}, used_totals{};
@@ -376,6 +377,7 @@ int sebm25_create(int device, sebm25_index** out) {
     sebm25_index* ix = new (std::nothrow) sebm25_index();
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
+    if (const char* e = getenv("SEBM25_SCORE_WINDOW")) ix->score_window = atoi(e) > 1024 ? 2048 : 1024;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     *out = ix;
     return SEBM25_OK;
@@ -662,9 +664,19 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
             plan.push_back({it, q_len[q] / ns});
         }
     }
-    std::stable_sort(plan.begin(), plan.end(), [](const Planned& a, const Planned& b) { return a.len > b.len; });
+    // fast-path items (few lists) first, each group longest first so the tail of the launch is short work
+    const uint32_t fast_t = score_fast_max_terms();
+    std::stable_sort(plan.begin(), plan.end(), [fast_t](const Planned& a, const Planned& b) {
+        const bool fa = a.it.n_terms <= fast_t, fb = b.it.n_terms <= fast_t;
+        if (fa != fb) return fa;
+        return a.len > b.len;
+    });
     std::vector<QItem> items(plan.size());
-    for (size_t i = 0; i < plan.size(); ++i) items[i] = plan[i].it;
+    uint32_t n_fast = 0;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        items[i] = plan[i].it;
+        n_fast += plan[i].it.n_terms <= fast_t;
+    }
 
     // ---- device buffers
     const size_t qk = (size_t)n_queries * k, tk = (size_t)std::max(n_tmp, 1u) * k;
@@ -723,7 +735,7 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     a.tmp_unit = ix->t_unit.as<uint32_t>(); a.tmp_score = ix->t_score.as<double>(); a.tmp_matched = ix->t_mat.as<uint32_t>();
     a.tmp_tie = ix->t_tie.as<uint32_t>(); a.tmp_count = ix->t_count.as<uint32_t>();
     phase_begin(ix, "score_topk");
-    launch_score(a, ix->stream);
+    launch_score(a, n_fast, ix->score_window, ix->stream);
     phase_end(ix);
     if (n_tmp) {
         MergeArgs m{};

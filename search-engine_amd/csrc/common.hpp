@@ -159,7 +159,8 @@ struct ScoreArgs {
     uint32_t *tmp_unit, *tmp_matched, *tmp_tie, *tmp_count;
     double* tmp_score;
 };
-void launch_score(const ScoreArgs& a, hipStream_t st);
+void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st);
+uint32_t score_fast_max_terms();
 struct MergeArgs {
     uint32_t n_queries, k;
     // per query: lists [first[q], first[q] + n[q]) of the input set; n[q] == 0 -> leave output alone

@@ -238,6 +238,144 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
+// Fast path for queries with at most FAST_T lists.  Each list keeps its next 64 postings in
+// registers, loaded one window ahead, so a window normally touches no global memory on its
+// critical path; the doc ids first touched in a window are appended to a dense list, so the
+// harvest offers 64 candidates per step instead of scanning a sparse bitmap.
+constexpr int FAST_T = 4;
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int CAP, int WINSZ>
+__global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
+    __shared__ __align__(16) double acc[WINSZ];
+    __shared__ unsigned char cnt[WINSZ];
+    __shared__ uint32_t touched[WINSZ / 32];
+    __shared__ unsigned short olist[WINSZ];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+
+    const QItem it = a.items[blockIdx.x];
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t T = it.n_terms;
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+
+    uint32_t my_cur = 0, my_end = 0;
+    double my_idf = 0.0;
+    if (lane < T) {
+        const uint32_t term = a.q_terms[it.term_off + lane];
+        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
+        my_idf = a.idf_used[term];
+    }
+    uint32_t cur[FAST_T], end[FAST_T], bu[FAST_T];
+    float bw[FAST_T];
+    double idf[FAST_T];
+#pragma unroll
+    for (int t = 0; t < FAST_T; ++t) {
+        cur[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
+        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
+        idf[t] = readlane_f64(my_idf, t);
+        const uint32_t i = cur[t] + lane;
+        const bool ok = i < end[t];
+        bu[t] = ok ? a.post_unit[i] : INF;
+        bw[t] = ok ? a.post_w[i] : 0.f;
+    }
+    if (lane < WINSZ / 32) touched[lane] = 0;
+    TopK<CAP> tk;
+    tk.init(topk_mem);
+    uint32_t n_o = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        uint32_t nxt = INF;
+#pragma unroll
+        for (int t = 0; t < FAST_T; ++t)
+            if (cur[t] < end[t]) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readfirstlane((int)bu[t]));
+        if (nxt == INF) break;
+        const uint32_t base = nxt & ~31u;
+        const uint64_t wend = (uint64_t)base + WINSZ;
+
+#pragma unroll
+        for (int t = 0; t < FAST_T; ++t) {
+            if (cur[t] < end[t]) {
+                uint32_t c = cur[t];
+                uint32_t u = bu[t];
+                float w = bw[t];
+                while (true) {
+                    const bool in = u != INF && (uint64_t)u < wend;
+                    const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                    bool first = false;
+                    uint32_t idx = 0;
+                    if (in) {
+                        const double v = __dmul_rn(idf[t], (double)w);
+                        idx = u - base;
+                        const uint32_t bit = 1u << (idx & 31u);
+                        const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                        first = !(old & bit);
+                        if (first) {
+                            acc[idx] = v;
+                            cnt[idx] = 1;
+                        } else {
+                            acc[idx] = __dadd_rn(acc[idx], v);
+                            cnt[idx] = (unsigned char)(cnt[idx] + 1);
+                        }
+                    }
+                    const uint64_t om = __ballot(first);
+                    if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
+                    n_o += (uint32_t)__popcll(om);
+                    c += n_in;
+                    if (n_in < 64) break;
+                    const uint32_t i = c + lane;  // the window holds more of this list
+                    const bool ok = i < end[t];
+                    u = ok ? a.post_unit[i] : INF;
+                    w = ok ? a.post_w[i] : 0.f;
+                }
+                if (c != cur[t]) {  // refill ahead of the next window
+                    cur[t] = c;
+                    const uint32_t i = c + lane;
+                    const bool ok = i < end[t];
+                    bu[t] = ok ? a.post_unit[i] : INF;
+                    bw[t] = ok ? a.post_w[i] : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // harvest: every doc id touched in this window, 64 per step
+        for (uint32_t o0 = 0; o0 < n_o; o0 += 64) {
+            const bool has = o0 + lane < n_o;
+            double s = 0.0;
+            uint32_t m = 0, unit = 0, tie = 0;
+            if (has) {
+                const uint32_t idx = olist[o0 + lane];
+                s = acc[idx];
+                m = cnt[idx];
+                touched[idx >> 5] = 0;
+                unit = base + idx;
+                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+            }
+            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
+        }
+        n_o = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const size_t o = (size_t)it.out_slot * a.k;
+    if (it.direct)
+        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                     a.out_count + it.out_slot);
+    else
+        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+}
+
 // one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
 template <int CAP>
 __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
@@ -266,16 +404,35 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 
 }  // namespace
 
-void launch_score(const ScoreArgs& a, hipStream_t st) {
-    if (a.n_items == 0) return;
-    dim3 grid(a.n_items), block(64);
-    if (a.k <= 64)
-        hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, a);
-    else if (a.k <= 256)
-        hipLaunchKernelGGL(k_score<512>, grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL(k_score<4096>, grid, block, 0, st, a);
+// items [0, n_fast) have at most FAST_T lists, the rest use the general kernel
+void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st) {
+    if (n_fast) {
+        dim3 grid(n_fast), block(64);
+        if (a.k <= 64) {
+            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<128, 1024>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_fast<128, 2048>), grid, block, 0, st, a);
+        } else if (a.k <= 256) {
+            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<512, 1024>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_fast<512, 2048>), grid, block, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((k_score_fast<4096, 1024>), grid, block, 0, st, a);
+        }
+    }
+    if (a.n_items > n_fast) {
+        ScoreArgs b = a;
+        b.items = a.items + n_fast;
+        b.n_items = a.n_items - n_fast;
+        dim3 grid(b.n_items), block(64);
+        if (a.k <= 64)
+            hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, b);
+        else if (a.k <= 256)
+            hipLaunchKernelGGL(k_score<512>, grid, block, 0, st, b);
+        else
+            hipLaunchKernelGGL(k_score<4096>, grid, block, 0, st, b);
+    }
 }
+
+uint32_t score_fast_max_terms() { return FAST_T; }
 
 void launch_merge(const MergeArgs& a, hipStream_t st) {
     if (a.n_queries == 0) return;
