@@ -275,18 +275,21 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
         my_idf = a.idf_used[term];
     }
-    uint32_t cur[FAST_T], end[FAST_T], bu[FAST_T];
-    float bw[FAST_T];
+    // per list: cursor, end, and the next 2 x 64 postings in registers
+    uint32_t cur[FAST_T], end[FAST_T], bu0[FAST_T], bu1[FAST_T];
+    float bw0[FAST_T], bw1[FAST_T];
     double idf[FAST_T];
 #pragma unroll
     for (int t = 0; t < FAST_T; ++t) {
         cur[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
         end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
         idf[t] = readlane_f64(my_idf, t);
-        const uint32_t i = cur[t] + lane;
-        const bool ok = i < end[t];
-        bu[t] = ok ? a.post_unit[i] : INF;
-        bw[t] = ok ? a.post_w[i] : 0.f;
+        const uint32_t i0 = cur[t] + lane, i1 = i0 + 64u;
+        const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
+        bu0[t] = ok0 ? a.post_unit[i0] : INF;
+        bw0[t] = ok0 ? a.post_w[i0] : 0.f;
+        bu1[t] = ok1 ? a.post_unit[i1] : INF;
+        bw1[t] = ok1 ? a.post_w[i1] : 0.f;
     }
     if (lane < WINSZ / 32) touched[lane] = 0;
     TopK<CAP> tk;
@@ -298,52 +301,63 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         uint32_t nxt = INF;
 #pragma unroll
         for (int t = 0; t < FAST_T; ++t)
-            if (cur[t] < end[t]) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readfirstlane((int)bu[t]));
+            if (cur[t] < end[t]) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readfirstlane((int)bu0[t]));
         if (nxt == INF) break;
         const uint32_t base = nxt & ~31u;
         const uint64_t wend = (uint64_t)base + WINSZ;
+
+        // adds the in-window postings of one 64-posting chunk; returns how many there were
+        auto consume = [&](uint32_t u, float w, double idf_t) -> uint32_t {
+            const bool in = u != INF && (uint64_t)u < wend;
+            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+            bool first = false;
+            uint32_t idx = 0;
+            if (in) {
+                const double v = __dmul_rn(idf_t, (double)w);
+                idx = u - base;
+                const uint32_t bit = 1u << (idx & 31u);
+                const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                first = !(old & bit);
+                if (first) {
+                    acc[idx] = v;
+                    cnt[idx] = 1;
+                } else {
+                    acc[idx] = __dadd_rn(acc[idx], v);
+                    cnt[idx] = (unsigned char)(cnt[idx] + 1);
+                }
+            }
+            const uint64_t om = __ballot(first);
+            if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
+            n_o += (uint32_t)__popcll(om);
+            return n_in;
+        };
 
 #pragma unroll
         for (int t = 0; t < FAST_T; ++t) {
             if (cur[t] < end[t]) {
                 uint32_t c = cur[t];
-                uint32_t u = bu[t];
-                float w = bw[t];
-                while (true) {
-                    const bool in = u != INF && (uint64_t)u < wend;
-                    const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-                    bool first = false;
-                    uint32_t idx = 0;
-                    if (in) {
-                        const double v = __dmul_rn(idf[t], (double)w);
-                        idx = u - base;
-                        const uint32_t bit = 1u << (idx & 31u);
-                        const uint32_t old = atomicOr(&touched[idx >> 5], bit);
-                        first = !(old & bit);
-                        if (first) {
-                            acc[idx] = v;
-                            cnt[idx] = 1;
-                        } else {
-                            acc[idx] = __dadd_rn(acc[idx], v);
-                            cnt[idx] = (unsigned char)(cnt[idx] + 1);
-                        }
-                    }
-                    const uint64_t om = __ballot(first);
-                    if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
-                    n_o += (uint32_t)__popcll(om);
+                uint32_t n_in = consume(bu0[t], bw0[t], idf[t]);
+                c += n_in;
+                if (n_in == 64) {
+                    n_in = consume(bu1[t], bw1[t], idf[t]);
                     c += n_in;
-                    if (n_in < 64) break;
-                    const uint32_t i = c + lane;  // the window holds more of this list
-                    const bool ok = i < end[t];
-                    u = ok ? a.post_unit[i] : INF;
-                    w = ok ? a.post_w[i] : 0.f;
+                    while (n_in == 64) {  // a dense list: the window holds more than 128 of its postings
+                        const uint32_t i = c + lane;
+                        const bool ok = i < end[t];
+                        n_in = consume(ok ? a.post_unit[i] : INF, ok ? a.post_w[i] : 0.f, idf[t]);
+                        c += n_in;
+                    }
                 }
-                if (c != cur[t]) {  // refill ahead of the next window
+                if (c != cur[t]) {
+                    // refill two chunks ahead: the second one brings the lines of later windows into
+                    // the cache long before they are needed
                     cur[t] = c;
-                    const uint32_t i = c + lane;
-                    const bool ok = i < end[t];
-                    bu[t] = ok ? a.post_unit[i] : INF;
-                    bw[t] = ok ? a.post_w[i] : 0.f;
+                    const uint32_t i0 = c + lane, i1 = i0 + 64u;
+                    const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
+                    bu0[t] = ok0 ? a.post_unit[i0] : INF;
+                    bw0[t] = ok0 ? a.post_w[i0] : 0.f;
+                    bu1[t] = ok1 ? a.post_unit[i1] : INF;
+                    bw1[t] = ok1 ? a.post_w[i1] : 0.f;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
