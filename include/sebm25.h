@@ -114,7 +114,9 @@ int sebm25_set_stream(sebm25_index* ix, void* hip_stream);
  *   totals  = the three document aggregates of bm25_stats.py:9,12
  *   doc_len = per web doc, sum of tf over its body (field 4) rows.
  * Posting weight (search_service.py:19-27 and :84-87): web  w = sum_f tf_f * W[f],
- * W = {1: 3.2, 2: 1.7, else 1.0}; news w = sum tf; summed in double, stored as float.
+ * W = {1: 3.2, 2: 1.7, else 1.0}; news w = sum tf.  Stored exactly, in tenths, as a 32-bit
+ * integer (32 tf_title + 17 tf_description + 10 tf_other; 10 tf for news): a (term, unit) whose
+ * weight exceeds 2^32 - 1 tenths returns SEBM25_E_RANGE.
  * Postings of web docs that are not 'done' are counted in df (bm25_stats.py has no status
  * filter on tokens) but left out of the index (search_service.py:32).
  */
@@ -177,10 +179,11 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
 /*
  * Copies the CSR out (any pointer may be NULL): for term t, web postings are
  * [row_ptr[t], news_ptr[t]) and news postings [news_ptr[t], row_ptr[t+1]), each in ascending
- * unit order.  row_ptr has n_terms + 1 entries, news_ptr n_terms, post_* n_postings.
+ * unit order.  row_ptr has n_terms + 1 entries, news_ptr n_terms, post_* n_postings;
+ * post_weight_tenths is the posting weight times ten (an exact integer).
  */
 int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit,
-                        float* post_weight);
+                        uint32_t* post_weight_tenths);
 
 /* ---- scoring + top-k: replaces the SQL executed at app/api/search_service.py:319-320 and
  *      :351-352 (SEARCH_SQL :13-40, FALLBACK_SEARCH_SQL :42-66, NEWS_SEARCH_SQL :68-101) ------ */
@@ -189,7 +192,8 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
  * Batched scoring.  Query q has term ids q_terms[q_offsets[q] .. q_offsets[q+1]) (host arrays);
  * duplicate ids count once and ids >= n_terms match nothing (`t.term = ANY($1)`).
  * For each unit with at least one matching posting of the requested source:
- *   score   = sum over query terms (in the order given) of idf_used[t] * w(t, unit)   (double)
+ *   score   = sum over query terms (in the order given) of (idf_used[t] / 10) * w10(t, unit)
+ *             with w10 the integer weight in tenths; double arithmetic, no fused multiply-add
  *   matched = COUNT(DISTINCT t.term)
  * Results are ordered score DESC, url rank ASC and cut at k (`LIMIT $2`), k <= 2048.
  * Outputs (host or device, caller-allocated): out_unit/out_score/out_matched/out_tie hold

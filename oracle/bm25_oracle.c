@@ -149,7 +149,7 @@ struct orc_index {
     double *idf, *idf_used;
     uint64_t *row_ptr, *news_ptr;
     uint32_t* post_unit;
-    float* post_w;
+    uint32_t* post_w; /* posting weight in tenths: 32*tf_title + 17*tf_description + 10*tf_other (web), 10*tf (news) */
     orc_totals totals;
     uint64_t N;
     double avgdl;
@@ -248,7 +248,7 @@ orc_index* orc_build(const uint32_t* term_id, const uint32_t* unit_id, const uin
     ix->row_ptr = (uint64_t*)calloc((size_t)V + 1, sizeof(uint64_t));
     ix->news_ptr = (uint64_t*)calloc(V, sizeof(uint64_t));
     ix->post_unit = (uint32_t*)malloc(sizeof(uint32_t) * (R ? R : 1));
-    ix->post_w = (float*)malloc(sizeof(float) * (R ? R : 1));
+    ix->post_w = (uint32_t*)malloc(sizeof(uint32_t) * (R ? R : 1));
     uint64_t p = 0;
     for (uint32_t t = 0; t < V; ++t) {
         ix->row_ptr[t] = p;
@@ -257,15 +257,16 @@ orc_index* orc_build(const uint32_t* term_id, const uint32_t* unit_id, const uin
         for (uint64_t i = ix->term_start[t]; i < ix->term_start[t + 1];) {
             uint32_t st = ix->s_meta[i] & 3u, u = ix->s_unit[i];
             uint64_t j = i;
-            double w = 0.0;
+            uint64_t w = 0; /* exact: W = {3.2, 1.7, 1.0} are 32, 17, 10 tenths */
             while (j < ix->term_start[t + 1] && (ix->s_meta[j] & 3u) == st && ix->s_unit[j] == u) {
-                double x = (double)ix->s_tf[j];
-                w = w + (st == 1 ? x * field_weight(ix->s_meta[j] >> 2) : x);
+                uint32_t field = ix->s_meta[j] >> 2;
+                w += (uint64_t)ix->s_tf[j] * (st == 1 ? (field == 1 ? 32u : field == 2 ? 17u : 10u) : 10u);
                 ++j;
             }
+            if (w > 0xFFFFFFFFull) w = 0xFFFFFFFFull;
             if (st == 2 && !seen_news) { ix->news_ptr[t] = p; seen_news = 1; }
             if (st == 1) ix->df[t]++; /* COUNT(DISTINCT doc_id): any status, NULL (news) not counted */
-            if (st == 2 || ix->doc_done[u]) { ix->post_unit[p] = u; ix->post_w[p] = (float)w; ++p; }
+            if (st == 2 || ix->doc_done[u]) { ix->post_unit[p] = u; ix->post_w[p] = (uint32_t)w; ++p; }
             i = j;
         }
         if (!seen_news) ix->news_ptr[t] = p;
@@ -302,7 +303,7 @@ const uint32_t* orc_doc_len(const orc_index* ix) { return ix->doc_len; }
 const uint64_t* orc_row_ptr(const orc_index* ix) { return ix->row_ptr; }
 const uint64_t* orc_news_ptr(const orc_index* ix) { return ix->news_ptr; }
 const uint32_t* orc_post_unit(const orc_index* ix) { return ix->post_unit; }
-const float* orc_post_weight(const orc_index* ix) { return ix->post_w; }
+const uint32_t* orc_post_weight(const orc_index* ix) { return ix->post_w; }
 void orc_get_totals(const orc_index* ix, orc_totals* out) { *out = ix->totals; }
 uint64_t orc_n_docs_stat(const orc_index* ix) { return ix->N; }
 double orc_avgdl(const orc_index* ix) { return ix->avgdl; }
@@ -380,14 +381,14 @@ uint32_t orc_search_csr(orc_index* ix, int source, const uint32_t* terms, uint32
     uint32_t m = dedupe_terms(ix, terms, nq, ts), n_touched = 0;
     for (uint32_t qi = 0; qi < m; ++qi) {
         uint32_t t = ts[qi];
-        double idf = ix->idf_used[t];
+        double idf10 = ix->idf_used[t] / 10.0; /* one division per list, then one multiply per posting */
         uint64_t b = source == 1 ? ix->row_ptr[t] : ix->news_ptr[t];
         uint64_t e = source == 1 ? ix->news_ptr[t] : ix->row_ptr[t + 1];
         for (uint64_t i = b; i < e; ++i) {
             uint32_t u = ix->post_unit[i];
             if (ix->last_term[u] == 0) ix->touched[n_touched++] = u;
             ix->cnt[u]++; ix->last_term[u] = qi + 1;
-            ix->acc[u] = ix->acc[u] + idf * (double)ix->post_w[i];
+            ix->acc[u] = ix->acc[u] + idf10 * (double)ix->post_w[i];
         }
     }
     free(ts);

@@ -52,7 +52,7 @@ const uint32_t* orc_doc_len(const orc_index* ix);
 const uint64_t* orc_row_ptr(const orc_index* ix);
 const uint64_t* orc_news_ptr(const orc_index* ix);
 const uint32_t* orc_post_unit(const orc_index* ix);
-const float* orc_post_weight(const orc_index* ix);
+const uint32_t* orc_post_weight(const orc_index* ix); /* weights in tenths (exact integers) */
 void orc_get_totals(const orc_index* ix, orc_totals* out);
 uint64_t orc_n_docs_stat(const orc_index* ix); /* N of bm25_stats.py:12-13 */
 double orc_avgdl(const orc_index* ix);
@@ -63,7 +63,8 @@ void orc_set_idf(orc_index* ix, const double* idf, const uint8_t* present);
 uint32_t orc_search_rows(orc_index* ix, int source, const uint32_t* terms, uint32_t n_terms_q,
                          uint32_t k, const uint32_t* url_rank, uint32_t unit_base,
                          uint32_t* out_unit, double* out_score, uint32_t* out_matched);
-/* scoring from the merged float postings (the arithmetic the GPU index performs) */
+/* scoring from the merged integer postings (the arithmetic the GPU index performs):
+ * score = sum over terms of (idf / 10.0) * weight_tenths */
 uint32_t orc_search_csr(orc_index* ix, int source, const uint32_t* terms, uint32_t n_terms_q,
                         uint32_t k, const uint32_t* url_rank, uint32_t unit_base,
                         uint32_t* out_unit, double* out_score, uint32_t* out_matched);

@@ -71,7 +71,7 @@ def lib():
         L.orc_finalize.argtypes = [C.c_void_p, p32, C.POINTER(Totals)]
         for name, rt in [("orc_df", p32), ("orc_idf", pd), ("orc_term_rows", p32), ("orc_doc_len", p32),
                          ("orc_row_ptr", p64), ("orc_news_ptr", p64), ("orc_post_unit", p32),
-                         ("orc_post_weight", pf)]:
+                         ("orc_post_weight", p32)]:
             getattr(L, name).restype = rt
             getattr(L, name).argtypes = [C.c_void_p]
         L.orc_get_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
@@ -197,7 +197,7 @@ class OracleIndex:
 
     @property
     def post_weight(self):
-        return self._arr("orc_post_weight", int(self.totals.n_postings), np.float32)
+        return self._arr("orc_post_weight", int(self.totals.n_postings), np.uint32)
 
     @property
     def n_docs_stat(self) -> int:
@@ -218,7 +218,7 @@ class OracleIndex:
 
     def search(self, terms, k, source=SRC_WEB, url_rank=None, unit_base=0, level="rows"):
         """Top-k of one query -> (unit[n], score[n], matched[n]); level 'rows' follows the SQL
-        formula row by row, 'csr' scores the merged float postings."""
+        formula row by row, 'csr' scores the merged integer postings."""
         terms = np.ascontiguousarray(terms, np.uint32)
         ur = None if url_rank is None else np.ascontiguousarray(url_rank, np.uint32)
         ou = np.empty(k, np.uint32)

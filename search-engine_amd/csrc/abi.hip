@@ -45,7 +45,7 @@ struct sebm25_index {
     DevBuf url_rank_web, url_rank_news;
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
     uint32_t* post_unit = nullptr;
-    float* post_w = nullptr;
+    uint32_t* post_w = nullptr;  // weights in tenths
 
     std::vector<uint32_t> h_row_ptr, h_news_ptr;
     bool host_ptrs_valid = false;
@@ -253,7 +253,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(ix->term_rows.p, 0, (size_t)V * 4, ix->stream));
         ix->post_unit = ix->sortA.as<uint32_t>();
-        ix->post_w = reinterpret_cast<float*>(ix->sortA.as<uint32_t>() + 1);
+        ix->post_w = ix->sortA.as<uint32_t>() + 1;
         ix->n_pass = 0;
     } else {
         // ---- stable LSD radix sort on the key bits of the packed row
@@ -306,7 +306,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         uint64_t* other = bufs[n_pass & 1];  // the buffer the last pass did not write
         // postings live in the free sort buffer: unit ids in its first half, weights in the second
         ix->post_unit = reinterpret_cast<uint32_t*>(other);
-        ix->post_w = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(other) + Rcap);
+        ix->post_w = reinterpret_cast<uint32_t*>(other) + Rcap;
 
         // ---- segmented reduction into postings: one contiguous range of rows per wavefront
         uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
@@ -326,7 +326,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         phase_end(ix);
         phase_begin(ix, "reduce_emit");
         launch_reduce_emit(sorted, R, chunk2, n_chunks, fmt, flags_dev, cnt_kept, cnt_wh, V, ix->post_unit, ix->post_w,
-                           row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal, ix->stream);
+                           row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal, err_dev, ix->stream);
         phase_end(ix);
         phase_begin(ix, "term_stats");
         launch_term_stats(V, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(),
@@ -344,7 +344,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     const uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
     if (dev_err & DEV_ERR_RANGE)
         return fail(ix, SEBM25_E_RANGE, "build: a row has term_id >= n_terms, a unit id outside its id space, an invalid "
-                                        "source_type, or a tf too wide for the packed row");
+                                        "source_type, a tf too wide for the packed row, or a posting weight above 2^32 - 1 tenths");
     if (dev_err & DEV_ERR_ORDER)
         return fail(ix, SEBM25_E_ORDER, "build: rows were declared unit-major (SEBM25_ROWS_UNIT_MAJOR) but are not");
     ix->P = h[0];
@@ -561,7 +561,8 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     return SEBM25_OK;
 }
 
-int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit, float* post_weight) {
+int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit,
+                        uint32_t* post_weight) {
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_postings: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);

@@ -503,9 +503,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_count(const uint64_t* ro
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows,
                                                              uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
                                                              const uint32_t* off_kept, const uint32_t* off_wh,
-                                                             uint32_t n_terms, uint32_t* post_unit, float* post_w,
+                                                             uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
                                                              uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                                                             uint32_t* rs_ptr, uint64_t* totals_out) {
+                                                             uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err) {
     const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const uint32_t lane = lane_id();
@@ -563,26 +563,28 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* row
                 if (fmt.src(r[j]) && (first || term != pterm || fmt.src(prev) == 0u)) news_ptr[term] = p;
             }
             if (fl.kept) {
-                // weight: web sum_f tf_f * W[f] (search_service.py:19-27), news sum tf (:84-87);
-                // double, multiply then add in row order, rounded once to float
+                // weight in tenths, exact: web sum_f tf_f * {32, 17, 10}[f] (W = 3.2 / 1.7 / 1.0,
+                // search_service.py:19-27), news 10 * sum tf (:84-87)
                 const uint64_t key = fmt.key(r[j]);
                 const bool news = fmt.src(r[j]) != 0u;
                 uint64_t rr = r[j];
                 uint64_t ii = i;
                 bool more = (i + 1 < R) && fmt.key(nxt) == key;
-                double w = 0.0;
+                uint64_t w = 0;
                 while (true) {
-                    const double x = (double)fmt.tf(rr);
                     const uint32_t fc = fmt.fc(rr);
-                    const double wf = fc == 1u ? 3.2 : fc == 2u ? 1.7 : 1.0;
-                    w = __dadd_rn(w, news ? x : __dmul_rn(x, wf));
+                    w += fmt.tf(rr) * (uint64_t)(news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u));
                     if (!more) break;
                     rr = (ii == i) ? nxt : rows[ii + 1];
                     ++ii;
                     more = (ii + 1 < R) && fmt.key(rows[ii + 1]) == key;
                 }
+                if (w > 0xFFFFFFFFull) {
+                    atomicOr(err, DEV_ERR_RANGE);
+                    w = 0xFFFFFFFFull;
+                }
                 post_unit[p] = fmt.unit(r[j]);
-                post_w[p] = (float)w;
+                post_w[p] = (uint32_t)w;
             }
             base_k += (uint32_t)__popcll(km);
             base_w += (uint32_t)__popcll(wm);
@@ -612,12 +614,12 @@ void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, 
 
 void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
                         const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
-                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                        uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st) {
+                        uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
+                        uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err, hipStream_t st) {
     const uint32_t wpb = RED_THREADS / 64;
     hipLaunchKernelGGL(k_reduce_emit, dim3((n_chunks + wpb - 1) / wpb), dim3(RED_THREADS), 0, st, rows, R, chunk_rows,
                        n_chunks, fmt, doc_flags, off_kept, off_wh, n_terms, post_unit, post_w, row_ptr, news_ptr, wh_ptr,
-                       rs_ptr, totals_out);
+                       rs_ptr, totals_out, err);
 }
 
 // ------------------------------------------------------------------ statistics ------------

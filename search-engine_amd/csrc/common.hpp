@@ -120,8 +120,8 @@ void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, 
                          const uint8_t* doc_flags, uint32_t* cnt_kept, uint32_t* cnt_wh, hipStream_t st);
 void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
                         const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
-                        uint32_t* post_unit, float* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                        uint32_t* rs_ptr, uint64_t* totals_out, hipStream_t st);
+                        uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
+                        uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err, hipStream_t st);
 void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
                        const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows, hipStream_t st);
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
@@ -144,7 +144,7 @@ struct ScoreArgs {
     const uint32_t* row_ptr;
     const uint32_t* news_ptr;
     const uint32_t* post_unit;
-    const float* post_w;
+    const uint32_t* post_w;  // posting weights in tenths
     const double* idf_used;
     const uint32_t* url_rank;  // may be null
     uint32_t unit_base;

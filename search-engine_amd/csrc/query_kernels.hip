@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
         my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
         my_end = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
-        my_idf = a.idf_used[term];
+        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
     }
     touched[lane] = 0;
     TopK<CAP> tk;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
                 const bool in = valid && (uint64_t)u < wend;
                 const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
                 if (in) {
-                    const double v = __dmul_rn(idf, (double)a.post_w[i]);
+                    const double v = __dmul_rn(idf, (double)a.post_w[i]);  // idf holds idf / 10, weights are in tenths
                     const uint32_t idx = u - base;
                     const uint32_t bit = 1u << (idx & 31u);
                     const uint32_t old = atomicOr(&touched[idx >> 5], bit);
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
         my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
         my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
-        my_idf = a.idf_used[term];
+        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
     }
     // per list: cursor, end, and the next 2 x 64 postings in registers
     uint32_t cur[FAST_T], end[FAST_T], bu0[FAST_T], bu1[FAST_T];
-    float bw0[FAST_T], bw1[FAST_T];
+    uint32_t bw0[FAST_T], bw1[FAST_T];
     double idf[FAST_T];
 #pragma unroll
     for (int t = 0; t < FAST_T; ++t) {
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         const uint32_t i0 = cur[t] + lane, i1 = i0 + 64u;
         const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
         bu0[t] = ok0 ? a.post_unit[i0] : INF;
-        bw0[t] = ok0 ? a.post_w[i0] : 0.f;
+        bw0[t] = ok0 ? a.post_w[i0] : 0u;
         bu1[t] = ok1 ? a.post_unit[i1] : INF;
-        bw1[t] = ok1 ? a.post_w[i1] : 0.f;
+        bw1[t] = ok1 ? a.post_w[i1] : 0u;
     }
     if (lane < WINSZ / 32) touched[lane] = 0;
     TopK<CAP> tk;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         const uint64_t wend = (uint64_t)base + WINSZ;
 
         // adds the in-window postings of one 64-posting chunk; returns how many there were
-        auto consume = [&](uint32_t u, float w, double idf_t) -> uint32_t {
+        auto consume = [&](uint32_t u, uint32_t w, double idf_t) -> uint32_t {
             const bool in = u != INF && (uint64_t)u < wend;
             const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
             bool first = false;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
                     while (n_in == 64) {  // a dense list: the window holds more than 128 of its postings
                         const uint32_t i = c + lane;
                         const bool ok = i < end[t];
-                        n_in = consume(ok ? a.post_unit[i] : INF, ok ? a.post_w[i] : 0.f, idf[t]);
+                        n_in = consume(ok ? a.post_unit[i] : INF, ok ? a.post_w[i] : 0u, idf[t]);
                         c += n_in;
                     }
                 }
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
                     const uint32_t i0 = c + lane, i1 = i0 + 64u;
                     const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
                     bu0[t] = ok0 ? a.post_unit[i0] : INF;
-                    bw0[t] = ok0 ? a.post_w[i0] : 0.f;
+                    bw0[t] = ok0 ? a.post_w[i0] : 0u;
                     bu1[t] = ok1 ? a.post_unit[i1] : INF;
-                    bw1[t] = ok1 ? a.post_w[i1] : 0.f;
+                    bw1[t] = ok1 ? a.post_w[i1] : 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
             }

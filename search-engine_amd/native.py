@@ -283,12 +283,12 @@ class Index:
         return i
 
     def postings(self):
-        """-> (row_ptr[V+1], news_ptr[V], post_unit[P], post_weight[P]) as numpy arrays."""
+        """-> (row_ptr[V+1], news_ptr[V], post_unit[P], post_weight_tenths[P]) as numpy arrays."""
         i = self.info()
         rp = np.empty(self.n_terms + 1, np.uint64)
         npz = np.empty(self.n_terms, np.uint64)
         pu = np.empty(i.n_postings, np.uint32)
-        pw = np.empty(i.n_postings, np.float32)
+        pw = np.empty(i.n_postings, np.uint32)
         self._check(self._L.sebm25_get_postings(self._h, rp.ctypes.data, npz.ctypes.data, pu.ctypes.data, pw.ctypes.data))
         return rp, npz, pu, pw
 

@@ -39,7 +39,7 @@ def assert_build_matches(ix, orc, idf_rtol=1e-14):
     np.testing.assert_array_equal(rp, orc.row_ptr)
     np.testing.assert_array_equal(nps, orc.news_ptr)
     np.testing.assert_array_equal(pu, orc.post_unit)
-    np.testing.assert_array_equal(pw.view(np.uint32), orc.post_weight.view(np.uint32))
+    np.testing.assert_array_equal(pw, orc.post_weight)      # exact integer weights (tenths)
 
 
 def assert_topk_valid(got_unit, got_score, got_matched, ref_unit, ref_score, ref_matched, k, tie_of=lambda u: u,
