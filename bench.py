@@ -106,20 +106,17 @@ def main():
     ix.gen_corpus(spec, term, unit, tf, meta, wc)
     ix.set_unit_base(rank * args.docs, rank * args.articles)
 
-    df_buf = torch.zeros(args.vocab, dtype=torch.int32, device=dev)
-    tot_buf = torch.zeros(4, dtype=torch.int64, device=dev)
+    from search_engine_amd.sharded import ShardedIndex
+
+    sharded = ShardedIndex(ix, dev) if world > 1 else None
 
     def step():
         if world == 1:
             ix.build(term, unit, tf, meta, args.vocab, args.docs, args.articles, wc)
-            return
-        ix.build_local(term, unit, tf, meta, args.vocab, args.docs, args.articles, wc)
-        _, t = ix.local_stats(df_buf)
-        tot_buf.copy_(torch.tensor([t.n_done, t.n_wc, t.sum_wc, t.n_postings], dtype=torch.int64))
-        dist.all_reduce(df_buf)   # per-term document frequencies: SUM over shards (RCCL over xGMI)
-        dist.all_reduce(tot_buf)  # N, AVG numerator / denominator, posting count
-        tg = tot_buf.tolist()
-        ix.finalize(df_buf, se.DocTotals(*tg))
+        else:
+            # build_local -> all-reduce of df[V] and the document totals (RCCL over xGMI) -> idf
+            sharded.build(term, unit, tf, meta, args.vocab, args.docs, args.articles, wc,
+                          doc_base=rank * args.docs, article_base=rank * args.articles)
 
     def sync():
         if world > 1:
@@ -198,8 +195,6 @@ def main():
             tmax = torch.tensor([tq], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             tq = float(tmax.item())
-        st = ix.stats()
-        rp, nps, _, _ = (None, None, None, None)
         # postings read by the batch: sum over query terms of the web list length (= local df)
         df_local, _ = ix.local_stats()
         sum_df = int(df_local.astype(np.int64)[qs.reshape(-1)].sum())

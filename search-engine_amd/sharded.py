@@ -1,0 +1,94 @@
+"""Document-sharded index over the GPUs of one node: one process (rank) per GPU.
+
+Every rank holds the postings of a contiguous range of documents (and of news articles) with
+the full vocabulary.  The statistics job needs one exchange — per-term document frequencies
+and the three document totals are sums over shards, merged with an all-reduce (RCCL over xGMI
+when the process group's backend is "nccl") — after which every rank computes the same idf.
+A search scores the query batch on every shard, all-gathers the per-shard top-k lists and
+merges them on each rank with the same ordering rule, so the result is identical to the one
+an unsharded index returns.
+
+The reference runs this job on one coordinator against the shared database
+(app/batch/runner.py:43-52); its only sharding idiom is `mod(id, nodes)`
+(app/batch/duplicate_detection.py:56).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .native import SRC_NEWS, SRC_WEB, DocTotals
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous range [begin, end) of `n` units owned by `rank`."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+class ShardedIndex:
+    """`engine` is this rank's `native.Index` (anything with the same build_local / local_stats /
+    finalize / search / merge_topk methods works); `device` is where collective buffers live."""
+
+    def __init__(self, engine, device, group=None):
+        self.engine = engine
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._df = None
+        self._tot = torch.zeros(4, dtype=torch.int64, device=self.device)
+
+    # ---- statistics job
+    def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
+              doc_base=0, article_base=0, unit_major=True):
+        """Rows of this rank's documents (unit ids local to the shard); doc_base / article_base
+        are the global ids of its first document / article."""
+        e = self.engine
+        e.build_local(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags,
+                      unit_major=unit_major)
+        e.set_unit_base(doc_base, article_base)
+        if self._df is None or self._df.numel() != n_terms:
+            self._df = torch.zeros(n_terms, dtype=torch.int32, device=self.device)
+        _, t = e.local_stats(self._df)
+        if self.world > 1:
+            self._tot.copy_(torch.tensor([t.n_done, t.n_wc, t.sum_wc, t.n_postings], dtype=torch.int64))
+            dist.all_reduce(self._df, group=self.group)    # df[V]: SUM over shards
+            dist.all_reduce(self._tot, group=self.group)   # N, AVG numerator and denominator, posting count
+            g = self._tot.tolist()
+            t = DocTotals(*g)
+        e.finalize(self._df, t)
+        self.totals = t
+        return t
+
+    # ---- scoring
+    def search(self, queries, k, source=SRC_WEB):
+        """-> dict(unit, score, matched, count) of the global top-k (numpy arrays, global unit ids),
+        the same on every rank."""
+        e = self.engine
+        nq = len(queries)
+        dev = self.device
+        loc = dict(unit=torch.empty((nq, k), dtype=torch.int32, device=dev),
+                   score=torch.empty((nq, k), dtype=torch.float64, device=dev),
+                   matched=torch.empty((nq, k), dtype=torch.int32, device=dev),
+                   tie=torch.empty((nq, k), dtype=torch.int32, device=dev),
+                   count=torch.empty(nq, dtype=torch.int32, device=dev))
+        e.search(queries, k, source=source, out=loc)
+        if self.world == 1:
+            return {key: _to_numpy(v) for key, v in loc.items() if key != "tie"}
+        gathered = {}
+        for key, v in loc.items():
+            buf = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=dev)
+            dist.all_gather(list(buf.unbind(0)), v.contiguous(), group=self.group)   # per-shard top-k lists
+            gathered[key] = buf
+        out = dict(unit=torch.empty_like(loc["unit"]), score=torch.empty_like(loc["score"]),
+                   matched=torch.empty_like(loc["matched"]), tie=torch.empty_like(loc["tie"]),
+                   count=torch.empty_like(loc["count"]))
+        e.merge_topk(self.world, nq, k, gathered["unit"], gathered["score"], gathered["matched"], gathered["tie"],
+                     gathered["count"], out=out)
+        return {key: _to_numpy(v) for key, v in out.items() if key != "tie"}
+
+
+def _to_numpy(t: torch.Tensor) -> np.ndarray:
+    a = t.detach().cpu().numpy()
+    return a.view(np.uint32) if a.dtype == np.int32 else a

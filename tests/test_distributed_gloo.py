@@ -1,0 +1,127 @@
+"""The multi-rank path (shard -> all-reduce df/totals -> idf; per-shard top-k -> all-gather ->
+merge) run with world_size 2 over gloo on CPU.  The per-shard engine is the CPU oracle behind
+the interface of native.Index, so this exercises the product's collective logic
+(search-engine_amd/sharded.py) without a GPU; the GPU engine itself is covered by the gpu tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """native.Index look-alike backed by the CPU oracle (test stand-in for one GPU shard)."""
+
+    def __init__(self):
+        self.orc = None
+        self.base = (0, 0)
+
+    def build_local(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major=True):
+        from oracle import oracle as O
+        self.orc = O.OracleIndex(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags)
+
+    def set_unit_base(self, web, news):
+        self.base = (web, news)
+
+    def local_stats(self, df_out):
+        df_out.copy_(torch.from_numpy(self.orc.df.astype(np.int32)))
+        return df_out, self.orc.totals
+
+    def finalize(self, df, totals):
+        from oracle import oracle as O
+        self.orc.finalize(df.numpy().astype(np.uint32), O.Totals(totals.n_done, totals.n_wc, totals.sum_wc, totals.n_postings))
+
+    def search(self, queries, k, source, out):
+        base = self.base[0] if source == 1 else self.base[1]
+        for key in ("unit", "tie"):
+            out[key].fill_(-1)
+        out["score"].zero_(); out["matched"].zero_()
+        for i, q in enumerate(queries):
+            u, s, m = self.orc.search(np.asarray(q, np.uint32), k, source=source, unit_base=base, level="csr")
+            n = len(u)
+            out["count"][i] = n
+            out["unit"][i, :n] = torch.from_numpy(u.astype(np.int32))
+            out["tie"][i, :n] = torch.from_numpy(u.astype(np.int32))     # default tie-break key: global unit id
+            out["score"][i, :n] = torch.from_numpy(s)
+            out["matched"][i, :n] = torch.from_numpy(m.astype(np.int32))
+
+    def merge_topk(self, n_lists, nq, k, unit, score, matched, tie, count, out):
+        for q in range(nq):
+            c = []
+            for l in range(n_lists):
+                for i in range(int(count[l, q])):
+                    c.append((-float(score[l, q, i]), int(tie[l, q, i]) & 0xFFFFFFFF, int(unit[l, q, i]), int(matched[l, q, i])))
+            c.sort()
+            c = c[:k]
+            out["count"][q] = len(c)
+            for i, (ns, t, u, m) in enumerate(c):
+                out["unit"][q, i] = u; out["score"][q, i] = -ns; out["matched"][q, i] = m; out["tie"][q, i] = t
+
+
+def _worker(rank, world, port, n_docs, n_art, V, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from search_engine_amd.sharded import ShardedIndex, shard_range
+
+    d0, d1 = shard_range(n_docs, rank, world)
+    a0, a1 = shard_range(n_art, rank, world)
+    c = O.gen_corpus(O.make_spec(n_terms=V, n_docs=d1 - d0, n_articles=a1 - a0, doc_begin=d0, article_begin=a0,
+                                 body_min=30, body_max=90))
+    sh = ShardedIndex(OracleEngine(), "cpu")
+    t = sh.build(c["term_id"], c["unit_id"], c["tf"], c["meta"], V, d1 - d0, a1 - a0, c["word_count"],
+                 doc_base=d0, article_base=a0)
+    qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 20, 3)
+    web = sh.search(qs, 12, source=1)
+    news = sh.search(qs, 12, source=2)
+    np.savez(result_path % rank, df=sh.engine.orc.df, idf=sh.engine.orc.idf, df_global=sh._df.numpy(),
+             totals=np.array([t.n_done, t.n_wc, t.sum_wc, t.n_postings]), n=sh.engine.orc.n_docs_stat,
+             avgdl=sh.engine.orc.avgdl, **{f"web_{k}": v for k, v in web.items()}, **{f"news_{k}": v for k, v in news.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_build_and_search_equal_unsharded(tmp_path):
+    from oracle import oracle as O
+
+    n_docs, n_art, V, world = 400, 50, 2000, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = str(tmp_path / "rank%d.npz")
+    mp.start_processes(_worker, args=(world, port, n_docs, n_art, V, path), nprocs=world, join=True, start_method="spawn")
+    full = O.gen_corpus(O.make_spec(n_terms=V, n_docs=n_docs, n_articles=n_art, body_min=30, body_max=90))
+    orc = O.OracleIndex(full["term_id"], full["unit_id"], full["tf"], full["meta"], V, n_docs, n_art, full["word_count"])
+    qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 20, 3)
+    r = [np.load(path % i) for i in range(world)]
+    np.testing.assert_array_equal(r[0]["df"] + r[1]["df"], orc.df)          # local df sums to the global df
+    for x in r:
+        np.testing.assert_array_equal(x["df_global"].view(np.uint32), orc.df)   # all-reduced, bit-exact
+        np.testing.assert_array_equal(x["idf"], orc.idf)                    # identical idf on every rank
+        assert int(x["n"]) == orc.n_docs_stat and float(x["avgdl"]) == orc.avgdl
+        t = orc.totals
+        assert x["totals"].tolist() == [t.n_done, t.n_wc, t.sum_wc, t.n_postings]
+        for src, name in ((1, "web"), (2, "news")):
+            for i, q in enumerate(qs):
+                u, sc, m = orc.search(q, 12, source=src, level="csr")
+                n = int(x[f"{name}_count"][i])
+                assert n == len(u)
+                np.testing.assert_array_equal(x[f"{name}_unit"][i, :n], u)
+                np.testing.assert_array_equal(x[f"{name}_score"][i, :n], sc)
+                np.testing.assert_array_equal(x[f"{name}_matched"][i, :n], m)
+
+
+def test_shard_ranges_cover_everything():
+    from search_engine_amd.sharded import shard_range
+
+    for n in (0, 1, 7, 1000, 10_000_001):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(n, g, world) for g in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[g][1] == r[g + 1][0] for g in range(world - 1))
