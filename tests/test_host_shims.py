@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference interface: tokenizer, query context, intent re-rank, the
+`run()` job and the `perform_*_search` entry points, end to end over a sqlite database that has
+the reference's tables.  On CPU the per-index engine is the oracle behind native.Index's
+interface (test stand-in); the gpu-marked test runs the same flow on the real GPU index."""
+import asyncio
+import math
+import sqlite3
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from search_engine_amd.api import search_service as ss
+from search_engine_amd.batch import bm25_stats
+from search_engine_amd.engine import SearchEngine
+from search_engine_amd.store import SqlStore, url_ranks
+from search_engine_amd.tokenizer import porter_stem, tokenize
+
+DDL = """
+CREATE TABLE documents (id INTEGER PRIMARY KEY, url TEXT UNIQUE NOT NULL, title TEXT, description TEXT, content TEXT,
+                        word_count INT, status TEXT DEFAULT 'done');
+CREATE TABLE news_feeds (feed_url TEXT PRIMARY KEY, home_url TEXT, name TEXT, link TEXT, image TEXT, discovered_by_url TEXT,
+                         last_published TEXT, last_fetched TEXT, next_fetch_at TEXT, publish_rate_per_hour REAL);
+CREATE TABLE news_articles (url TEXT PRIMARY KEY, feed_url TEXT NOT NULL, title TEXT, description TEXT, image TEXT,
+                            content TEXT, author TEXT, published_at TEXT);
+CREATE TABLE tokens (doc_id INTEGER, term TEXT NOT NULL, field INTEGER NOT NULL, frequency INT NOT NULL,
+                     article_url TEXT, source_type INTEGER DEFAULT 1);
+CREATE TABLE term_statistics (term TEXT PRIMARY KEY, doc_frequency BIGINT NOT NULL, idf DOUBLE PRECISION NOT NULL,
+                              avg_doc_len DOUBLE PRECISION NOT NULL);
+"""
+
+PAGES = [
+    (11, "https://gpu.example/radix-sort", "Radix sort on GPUs", "Sorting keys with radix passes", "radix sort gpu keys passes histogram scatter radix"),
+    (12, "https://gpu.example/bm25", "BM25 ranking", "Ranking documents with BM25", "ranking documents bm25 idf term frequency ranking"),
+    (15, "https://db.example/postgres-sort", "Sorting in PostgreSQL", None, "postgres sort order by limit sorting rows"),
+    (20, "https://news.example/archive", "Archive", "Old stories about sorting", "archive stories"),
+    (21, "https://gpu.example/draft", "Radix draft", "unfinished", "radix radix radix"),
+]
+ARTICLES = [
+    ("https://news.example/a1", "https://news.example/feed", "GPU radix sort record", "A new record", "radix sort record gpu", "Ann", "2026-02-01T10:00:00"),
+    ("https://news.example/a2", "https://news.example/feed", "Ranking functions", "", "bm25 ranking functions", None, None),
+]
+
+
+def make_db(path):
+    db = sqlite3.connect(path)
+    db.executescript(DDL)
+    db.execute("INSERT INTO news_feeds VALUES ('https://news.example/feed','https://news.example','Example News',NULL,NULL,NULL,"
+               "'2026-02-01T10:00:00',NULL,NULL,0.5)")
+    for doc_id, url, title, desc, content in PAGES:
+        status = "processing" if doc_id == 21 else "done"
+        db.execute("INSERT INTO documents VALUES (?,?,?,?,?,?,?)", (doc_id, url, title, desc, content, len(content.split()), status))
+        for field, text in ((1, title), (2, desc), (4, content)):          # worker.py:192-194, :230-239
+            for term, freq in tokenize(text or "").items():
+                db.execute("INSERT INTO tokens VALUES (?,?,?,?,NULL,1)", (doc_id, term, field, freq))
+    for url, feed, title, desc, content, author, pub in ARTICLES:
+        db.execute("INSERT INTO news_articles VALUES (?,?,?,?,NULL,?,?,?)", (url, feed, title, desc, content, author, pub))
+        for term, freq in tokenize(" ".join([title, desc, content])).items():   # news_fetcher.py:298-311
+            db.execute("INSERT INTO tokens VALUES (NULL,?,4,?,?,2)", (term, freq, url))
+    db.commit()
+    db.close()
+
+
+class OracleBackedIndex:
+    """native.Index look-alike on the CPU oracle: lets the host logic run without a GPU."""
+
+    def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major=True):
+        self.orc = O.OracleIndex(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags)
+        self.rank = {1: None, 2: None}
+
+    def stats(self):
+        o = self.orc
+        return dict(df=o.df, idf=o.idf, term_rows=o.term_rows, n_docs=o.n_docs_stat, avgdl=o.avgdl)
+
+    def set_url_rank(self, source, rank):
+        self.rank[source] = rank
+
+    def set_idf(self, idf, present=None):
+        self.orc.set_idf(idf, present)
+
+    def search(self, queries, k, source=1):
+        u, s, m = self.orc.search(np.asarray(queries[0], np.uint32), k, source=source, url_rank=self.rank[source], level="csr")
+        n = len(u)
+        return dict(unit=u.reshape(1, n), score=s.reshape(1, n), matched=m.reshape(1, n), count=np.array([n]))
+
+    def close(self):
+        pass
+
+
+def sql_reference_rows(path, terms, limit):
+    """The reference's web statement on the same database (its term_statistics already written)."""
+    db = sqlite3.connect(path)
+    ph = ",".join("?" * len(terms))
+    rows = db.execute(f"""
+        WITH scored AS (SELECT d.id, d.title, d.description, d.url,
+            SUM(t.frequency * COALESCE(ts.idf, 1.0) * CASE t.field WHEN 1 THEN 3.2 WHEN 2 THEN 1.7 ELSE 1.0 END) AS token_score,
+            COUNT(DISTINCT t.term) AS matched_terms
+          FROM tokens t JOIN documents d ON d.id = t.doc_id LEFT JOIN term_statistics ts ON ts.term = t.term
+          WHERE d.status = 'done' AND t.term IN ({ph}) GROUP BY d.id, d.title, d.description, d.url)
+        SELECT title, COALESCE(description, ''), url, token_score, matched_terms FROM scored
+        ORDER BY token_score DESC, url ASC LIMIT ?""", list(terms) + [limit]).fetchall()
+    db.close()
+    return rows
+
+
+def run_flow(tmp_path, index_factory):
+    path = str(tmp_path / "se.db")
+    make_db(path)
+    store = SqlStore(lambda: sqlite3.connect(path))
+    engine = SearchEngine(store, index_factory=index_factory)
+    bm25_stats.configure(engine)
+    ss.configure(engine)
+
+    async def flow():
+        await asyncio.gather(bm25_stats.run(), asyncio.sleep(0))      # shares a loop with sibling jobs (runner.py:52)
+        web = await ss.perform_web_search(q="The radix sorting", limit=2, offset=0)
+        news = await ss.perform_news_search(q="radix sort")
+        empty = await ss.perform_web_search(q="the of and")
+        return web, news, empty
+
+    web, news, empty = asyncio.run(flow())
+    # ---- term_statistics was replaced with what the SQL job would have written
+    db = sqlite3.connect(path)
+    got = {t: (df, idf, al) for t, df, idf, al in db.execute("SELECT * FROM term_statistics")}
+    n_done = db.execute("SELECT COUNT(*) FROM documents WHERE status='done'").fetchone()[0]
+    avg = db.execute("SELECT AVG(word_count) FROM documents WHERE status='done'").fetchone()[0]
+    want = db.execute("SELECT term, COUNT(DISTINCT doc_id) FROM tokens GROUP BY term").fetchall()
+    db.close()
+    assert set(got) == {t for t, _ in want}
+    for term, df in want:
+        assert got[term][0] == df
+        assert got[term][1] == pytest.approx(math.log((n_done - df + 0.5) / (df + 0.5) + 1), rel=1e-14)
+        assert got[term][2] == pytest.approx(avg, rel=1e-15)
+    assert got["radix"][0] == 2          # docs 11 and 21 (any status); the news row adds nothing
+    assert got["record"][0] == 0         # news-only term
+    # ---- web search: candidates equal the reference statement's rows, then the intent re-rank
+    svc = ss.search_service
+    ctx = svc._search_context("The radix sorting", 2, 0)
+    assert ctx["query_terms"] == ["radix", "sort"] and ctx["candidate_limit"] == 202
+    rows = engine.score_web(ctx["query_terms"], ctx["candidate_limit"])
+    ref = sql_reference_rows(path, ctx["query_terms"], ctx["candidate_limit"])
+    assert [r[:3] for r in rows] == [r[:3] for r in ref]
+    assert [r[4] for r in rows] == [r[4] for r in ref]
+    np.testing.assert_allclose([r[3] for r in rows], [r[3] for r in ref], rtol=1e-12)
+    assert "https://gpu.example/draft" not in [r[2] for r in rows]     # status != 'done'
+    expect = svc._rank_web_rows(ref, context=ctx)
+    assert [i.url for i in web.results] == [i.url for i in expect[:2]]
+    np.testing.assert_allclose([i.score for i in web.results], [i.score for i in expect[:2]], rtol=1e-12)
+    assert web.count == max(len(expect), 0 + len(web.results)) and web.results[0].url == "https://gpu.example/radix-sort"
+    # ---- news: statement order is kept, +8 bonus, feed attached
+    assert [i.url for i in news.results] == ["https://news.example/a1"]
+    assert news.results[0].feed.name == "Example News" and news.results[0].author == "Ann"
+    assert news.results[0].published_at == "2026-02-01T10:00:00"
+    assert empty.results == [] and empty.count == 0
+    return engine
+
+
+def test_flow_on_cpu_stand_in(tmp_path):
+    run_flow(tmp_path, OracleBackedIndex)
+
+
+@pytest.mark.gpu
+def test_flow_on_gpu(tmp_path):
+    engine = run_flow(tmp_path, None)          # default factory: native.Index on cuda:0
+    engine.load_idf_from_table()               # COALESCE path: same table, same results
+    rows = engine.score_web(["radix", "sort"], 50)
+    assert rows[0][2] == "https://gpu.example/radix-sort"
+    engine.index.close()
+
+
+def test_candidate_limit_formula():
+    svc = ss.SearchService()
+    f = lambda limit, offset: svc._search_context("radix", limit, offset)["candidate_limit"]   # noqa: E731
+    assert f(10, 0) == 210 and f(20, 0) == 220 and f(100, 0) == 1000 and f(100, 1900) == 2000 and f(1, 5000) == 2000
+    assert svc._search_context("of the", 10, 0) is None
+
+
+def test_intent_score_hand_computed():
+    svc = ss.SearchService()
+    ctx = svc._search_context("radix sort", 10, 0)
+    s = svc._intent_score(token_score=math.e - 1, matched_terms=2, total_terms=2, query_phrase=ctx["query_phrase"],
+                          query_compact=ctx["query_compact"], query_words=ctx["query_words"],
+                          title="Radix sort on GPUs", description="About radix sort.", url="https://x.test/radix-sort")
+    # log1p(e-1)*12 + coverage 25 + all terms 40 + phrase in title 140, url 70, description 25, compact url 90
+    # + hits: title 2*22, url 2*16, compact url 2*12 + all-words bonuses 80 + 55 + 45
+    assert s == pytest.approx(12 + 25 + 40 + 140 + 70 + 25 + 90 + 44 + 32 + 24 + 80 + 55 + 45)
+    s2 = svc._intent_score(token_score=-3.0, matched_terms=1, total_terms=2, query_phrase="radix sort", query_compact="radixsort",
+                           query_words=["radix", "sort"], title="", description="", url="https://x.test/")
+    assert s2 == pytest.approx(12.5)            # negative token scores clamp to 0; half coverage
+
+
+def test_score_only_ranking_and_news_order():
+    svc = ss.SearchService()
+    ctx = svc._search_context("radix sort", 10, 0)
+    items = svc._rank_score_only_rows([(1.0, 1), (0.5, 2)], context=ctx)
+    assert [round(i.score, 6) for i in items] == sorted([round(math.log1p(1.0) * 12 + 12.5, 6), round(math.log1p(0.5) * 12 + 65, 6)], reverse=True)
+    row = lambda url, sc: ("t", "", url, None, None, None, None, None, None, None, None, None, None, None, None, sc, 1)   # noqa: E731
+    out = svc._rank_news_rows([row("https://b", 1.0), row("https://a", 9.0)], context=ctx)
+    assert [i.url for i in out] == ["https://b", "https://a"] and out[0].feed is None     # no re-sort
+
+
+def test_tokenizer_known_answers():
+    assert list(tokenize("The Quick brown foxes; the QUICK dog's 2 x86 cpus!").items()) == [
+        ("quick", 2), ("brown", 1), ("fox", 1), ("dog", 1), ("x86", 1), ("cpu", 1)]
+    pairs = {"caresses": "caress", "ponies": "poni", "cats": "cat", "feed": "feed", "plastered": "plaster",
+             "motoring": "motor", "sing": "sing", "conflated": "conflat", "troubled": "troubl", "sized": "size",
+             "hopping": "hop", "falling": "fall", "hissing": "hiss", "failing": "fail", "filing": "file", "happy": "happi",
+             "relational": "relat", "conditional": "condit", "digitizer": "digit", "vietnamization": "vietnam",
+             "operator": "oper", "feudalism": "feudal", "decisiveness": "decis", "hopefulness": "hope",
+             "formaliti": "formal", "sensitiviti": "sensit", "triplicate": "triplic", "electrical": "electr",
+             "goodness": "good", "revival": "reviv", "allowance": "allow", "inference": "infer", "adjustable": "adjust",
+             "replacement": "replac", "adoption": "adopt", "communism": "commun", "effective": "effect", "rate": "rate",
+             "cease": "ceas", "controll": "control", "roll": "roll", "running": "run", "sorting": "sort", "ranking": "rank"}
+    for w, s in pairs.items():
+        assert porter_stem(w) == s, w
+    assert porter_stem("dying") == "die" and porter_stem("skies") == "sky" and porter_stem("ties") == "tie"
+    assert porter_stem("by") == "by" and porter_stem("a") == "a"
+
+
+def test_url_ranks():
+    r = url_ranks(["https://b", "https://a", "https://c"])
+    assert r.tolist() == [1, 0, 2]
+    r = url_ranks(["B", "a", "C"], key=str.lower)
+    assert r.tolist() == [1, 0, 2]
