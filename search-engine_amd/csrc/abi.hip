@@ -274,6 +274,8 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ctx.fmt = fmt;
         ctx.n_terms = V; ctx.n_docs = in->n_docs; ctx.n_articles = in->n_articles;
         ctx.check_order = unit_major ? 1u : 0u;
+        ctx.debug = getenv("SEBM25_DEBUG") ? (uint32_t)atoi(getenv("SEBM25_DEBUG")) : 0u;
+        if (ctx.debug & 4u) ctx.check_order = 0;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
         ctx.err = err_dev;
 

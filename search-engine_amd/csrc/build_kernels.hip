@@ -25,12 +25,69 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int bits, bool valid
     return peers;
 }
 
+// The same set, found through LDS instead of one ballot per digit bit.  The group of the first
+// valid lane (the hot digit of a skewed or sorted round) is taken by one compare; every other
+// lane ORs its lane bit into a per-wave table slot chosen by the low MATCH_TAB_BITS digit bits,
+// reads the slot back (all lanes that share those bits), and the remaining high bits are settled
+// by ballots.  Slots are cleared again by their lowest lane.  tab: 2 words (lanes 0-31, 32-63)
+// per slot, all zero between calls.  A wave's LDS operations complete in issue order.
+constexpr int MATCH_TAB_BITS = 8;
+__device__ __forceinline__ uint64_t match_digit_lds(uint32_t* tab, uint32_t d, int bits, bool valid) {
+    const uint32_t lane = lane_id();
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) return 0;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __ffsll((unsigned long long)vm) - 1);
+    const bool in0 = valid && d == d0;
+    const uint64_t m0 = __ballot(in0);
+    const bool rest = valid && !in0;
+    uint64_t cand = 0;
+    if (__ballot(rest)) {
+        const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
+        if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
+        __builtin_amdgcn_wave_barrier();
+        if (rest) cand = *reinterpret_cast<const uint64_t*>(&tab[slot]);
+        const uint64_t raw = cand;
+        for (int b = MATCH_TAB_BITS; b < bits; ++b) {
+            const bool one = (d >> b) & 1u;
+            const uint64_t bal = __ballot(one);
+            cand &= one ? bal : ~bal;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (rest && (raw & lanemask_lt()) == 0) *reinterpret_cast<uint64_t*>(&tab[slot]) = 0ull;
+    }
+    return in0 ? m0 : cand;
+}
+
 __device__ __forceinline__ uint32_t field_code(uint32_t field) { return field == 1u ? 1u : field == 2u ? 2u : 0u; }
 
+// Cross-lane moves that stay in the vector ALU (DPP / readlane) instead of going through the LDS
+// crossbar as __shfl does: lane i <- lane i-1 (lane 0 keeps its own value), lane i <- lane i+1
+// (lane 63 keeps its own), and broadcasts of a fixed lane.
+__device__ __forceinline__ uint32_t lane_up1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_dn1(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint64_t lane_up1(uint64_t x) {
+    return ((uint64_t)lane_up1((uint32_t)(x >> 32)) << 32) | lane_up1((uint32_t)x);
+}
+__device__ __forceinline__ uint64_t lane_dn1(uint64_t x) {
+    return ((uint64_t)lane_dn1((uint32_t)(x >> 32)) << 32) | lane_dn1((uint32_t)x);
+}
+template <int L>
+__device__ __forceinline__ uint64_t lane_bcast(uint64_t x) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), L) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, L);
+}
+// wave-wide sum, uniform result: quad swaps and row mirrors (DPP), then one readlane per row
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141 /* row_half_mirror */, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140 /* row_mirror */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // ------------------------------------------------------------------ histogram (upsweep) ---
@@ -149,7 +206,8 @@ template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                uint64_t R, uint64_t chunk_rows, uint32_t G, int shift,
                                                                int bits, BuildCtx ctx, const uint32_t* chunk_off) {
-    __shared__ uint32_t whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then per-wave offsets
+    __shared__ unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then per-wave offsets
+    __shared__ uint32_t mtab[SORT_WAVES][2 << MATCH_TAB_BITS];     // per wave: lane masks per folded digit
     __shared__ uint64_t rows_s[SORT_TILE];                 // the tile, locally ordered by digit
     __shared__ uint32_t tile_start[SORT_MAX_BINS];         // first local slot of each digit
     __shared__ uint32_t bin_base[SORT_MAX_BINS];           // next global slot of each digit for this chunk
@@ -163,6 +221,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
     const uint64_t end = min(R, begin + chunk_rows);
     for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) bin_base[d] = chunk_off[(size_t)d * G + blockIdx.x];
     for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
+    for (uint32_t x = threadIdx.x; x < SORT_WAVES * (2u << MATCH_TAB_BITS); x += SORT_THREADS) (&mtab[0][0])[x] = 0;
     if (MODE != 2) dl_s[threadIdx.x] = 0;
     __syncthreads();
 
@@ -218,9 +277,9 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
                 const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
                 uint64_t r = ~0ull;
                 if (valid) {
-                    const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
+                    const bool bad = !(ctx.debug & 2u) && (term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
                                      unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
-                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
+                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u));
                     if (bad) {
                         atomicOr(ctx.err, DEV_ERR_RANGE);
                         term[j] = min(term[j], ctx.n_terms - 1u);  // keep every later index in range
@@ -232,14 +291,14 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
                 row[j] = r;
                 // unit-major check: (source, unit) must not decrease from one row to the next
                 const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit[j]) : ~0ull;
-                uint64_t prev = __shfl_up(ukey, 1);
+                uint64_t prev = lane_up1(ukey);
                 if (lane == 0) prev = carry;
-                carry = __shfl(ukey, 63);
+                carry = lane_bcast<63>(ukey);
                 if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
                 // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
                 // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
-                const uint32_t body = (valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
-                const uint64_t first_key = __shfl(ukey, 0);
+                const uint32_t body = (!(ctx.debug & 1u) && valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
+                const uint64_t first_key = lane_bcast<0>(ukey);
                 const bool uniform = __all(ukey == first_key);
                 uint32_t add = body;
                 bool do_add = body != 0u;
@@ -264,12 +323,12 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
             const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
             const bool valid = i < end;
             const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
-            const uint64_t peers = match_digit(d, bits, valid);
+            const uint64_t peers = match_digit_lds(mtab[wave], d, bits, valid);
             const int leader = __ffsll((unsigned long long)peers) - 1;
             uint32_t old = 0;
             if (valid && (int)lane == leader) {
                 old = whist[wave][d];
-                whist[wave][d] = old + (uint32_t)__popcll(peers);
+                whist[wave][d] = (unsigned short)(old + (uint32_t)__popcll(peers));
             }
             old = __shfl(old, leader < 0 ? 0 : leader);
             rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
@@ -283,7 +342,7 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
 #pragma unroll
             for (int w = 0; w < SORT_WAVES; ++w) {
                 const uint32_t c = whist[w][d];
-                whist[w][d] = run;
+                whist[w][d] = (unsigned short)run;
                 run += c;
             }
             tile_start[d] = run;
@@ -486,9 +545,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_count(const uint64_t* ro
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
             const uint64_t i = b0 + (uint64_t)j * 64u + lane;
-            uint64_t prev = __shfl_up(r[j], 1);
+            uint64_t prev = lane_up1(r[j]);
             if (lane == 0) prev = carry;
-            carry = __shfl(r[j], 63);
+            carry = lane_bcast<63>(r[j]);
             const RowFlags fl = row_flags(r[j], prev, i == 0, i < end, fmt, doc_flags);
             kept += (uint32_t)__popcll(__ballot(fl.kept));
             wh += (uint32_t)__popcll(__ballot(fl.webhead));
@@ -517,13 +576,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* row
     // rows past this wave's range are still loaded (they end runs that start inside it); the
     // next batch is loaded before the current one is processed
     uint64_t r[RED_ROUNDS], rn[RED_ROUNDS];
-    uint64_t after = 0, after_n = 0;
+    uint64_t after = 0, after2 = 0, after_n = 0, after2_n = 0;  // the two rows behind the batch
 #pragma unroll
     for (int j = 0; j < RED_ROUNDS; ++j) {
         const uint64_t i = begin + (uint64_t)j * 64u + lane;
         r[j] = i < R ? rows[i] : 0ull;
     }
     after = begin + RED_BATCH < R ? rows[begin + RED_BATCH] : 0ull;
+    after2 = begin + RED_BATCH + 1 < R ? rows[begin + RED_BATCH + 1] : 0ull;
     for (uint64_t b0 = begin; b0 < end; b0 += RED_BATCH) {
         const uint64_t nb0 = b0 + RED_BATCH;
         if (nb0 < end) {
@@ -533,17 +593,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* row
                 rn[j] = i < R ? rows[i] : 0ull;
             }
             after_n = nb0 + RED_BATCH < R ? rows[nb0 + RED_BATCH] : 0ull;
+            after2_n = nb0 + RED_BATCH + 1 < R ? rows[nb0 + RED_BATCH + 1] : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
             const uint64_t i = b0 + (uint64_t)j * 64u + lane;
             const bool valid = i < end;
-            uint64_t prev = __shfl_up(r[j], 1);
+            uint64_t prev = lane_up1(r[j]);
             if (lane == 0) prev = carry;
-            carry = __shfl(r[j], 63);
-            uint64_t nxt = __shfl_down(r[j], 1);
-            const uint64_t nxt_round0 = (j + 1 < RED_ROUNDS) ? __shfl(r[(j + 1 < RED_ROUNDS) ? j + 1 : j], 0) : after;
-            if (lane == 63) nxt = nxt_round0;
+            carry = lane_bcast<63>(r[j]);
+            // rows i+1 and i+2 through lane shifts; at the wave edge they are the next round's first lanes
+            const uint64_t e0 = (j + 1 < RED_ROUNDS) ? lane_bcast<0>(r[(j + 1 < RED_ROUNDS) ? j + 1 : j]) : after;
+            const uint64_t e1 = (j + 1 < RED_ROUNDS) ? lane_bcast<1>(r[(j + 1 < RED_ROUNDS) ? j + 1 : j]) : after2;
+            uint64_t r1 = lane_dn1(r[j]);
+            if (lane == 63) r1 = e0;
+            uint64_t r2 = lane_dn1(r1);
+            if (lane == 63) r2 = e1;
             const bool first = i == 0;
             const RowFlags fl = row_flags(r[j], prev, first, valid, fmt, doc_flags);
             const uint64_t km = __ballot(fl.kept), wm = __ballot(fl.webhead);
@@ -567,17 +632,19 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* row
                 // search_service.py:19-27), news 10 * sum tf (:84-87)
                 const uint64_t key = fmt.key(r[j]);
                 const bool news = fmt.src(r[j]) != 0u;
-                uint64_t rr = r[j];
-                uint64_t ii = i;
-                bool more = (i + 1 < R) && fmt.key(nxt) == key;
-                uint64_t w = 0;
-                while (true) {
-                    const uint32_t fc = fmt.fc(rr);
-                    w += fmt.tf(rr) * (uint64_t)(news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u));
-                    if (!more) break;
-                    rr = (ii == i) ? nxt : rows[ii + 1];
-                    ++ii;
-                    more = (ii + 1 < R) && fmt.key(rows[ii + 1]) == key;
+                auto tenths = [&](uint64_t x) -> uint64_t {
+                    const uint32_t fc = fmt.fc(x);
+                    return fmt.tf(x) * (uint64_t)(news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u));
+                };
+                const bool same1 = (i + 1 < R) && fmt.key(r1) == key;
+                const bool same2 = same1 && (i + 2 < R) && fmt.key(r2) == key;
+                uint64_t w = tenths(r[j]) + (same1 ? tenths(r1) : 0ull) + (same2 ? tenths(r2) : 0ull);
+                if (same2) {  // more than three rows of one (term, unit): not produced by the reference's writers
+                    for (uint64_t ii = i + 3; ii < R; ++ii) {
+                        const uint64_t x = rows[ii];
+                        if (fmt.key(x) != key) break;
+                        w += tenths(x);
+                    }
                 }
                 if (w > 0xFFFFFFFFull) {
                     atomicOr(err, DEV_ERR_RANGE);
@@ -602,6 +669,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* row
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) r[j] = rn[j];
         after = after_n;
+        after2 = after2_n;
     }
 }
 

@@ -100,6 +100,7 @@ struct BuildCtx {
     RowFmt fmt;
     uint32_t n_terms, n_docs, n_articles;
     uint32_t check_order;   // rows declared unit-major: verify
+    uint32_t debug;         // experiment switches (SEBM25_DEBUG): 1 skip body lengths, 2 skip validation
     uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
     uint32_t* err;          // device error word
 };
