@@ -226,7 +226,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
     HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
     HIP_TRY(ix, ix->doc_len.ensure(std::max<size_t>(in->n_docs, 1) * 4));
-    HIP_TRY(ix, ix->scalars.ensure(64));
+    HIP_TRY(ix, ix->scalars.ensure(64 + (size_t)DUMP_WORDS * 8));
     HIP_TRY(ix, hipMemsetAsync(ix->scalars.p, 0, 64, ix->stream));
     HIP_TRY(ix, hipMemsetAsync(ix->doc_len.p, 0, std::max<size_t>(in->n_docs, 1) * 4, ix->stream));
     uint64_t* scal = ix->scalars.as<uint64_t>();
@@ -262,7 +262,8 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         const int key_bits = 64 - key_lo;
         const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
         ix->n_pass = (uint32_t)n_pass;
-        uint32_t G = (uint32_t)std::min<uint64_t>((R + SORT_TILE - 1) / SORT_TILE, SORT_MAX_CHUNKS);
+        const uint32_t max_chunks = getenv("SEBM25_SORT_CHUNKS") ? (uint32_t)atoi(getenv("SEBM25_SORT_CHUNKS")) : SORT_MAX_CHUNKS;
+        uint32_t G = (uint32_t)std::min<uint64_t>((R + SORT_TILE - 1) / SORT_TILE, max_chunks);
         uint64_t chunk_rows = (R + G - 1) / G;
         chunk_rows = (chunk_rows + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
         G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
@@ -278,6 +279,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         if (ctx.debug & 4u) ctx.check_order = 0;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
         ctx.err = err_dev;
+        ctx.dump = scal + 8;
 
         static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6"};
         static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6"};

@@ -4,9 +4,9 @@
 // the reference (app/batch/bm25_stats.py:16-27) and the document aggregates at :9-13.
 //
 // Every kernel here is bandwidth-bound integer work: rows stream through in coalesced
-// 64-lane accesses with all loads of a tile issued before the first use, digit ranking uses
-// wave ballots, and each workgroup owns a contiguous chunk of rows so that the runs it appends
-// to a digit bin are adjacent in memory and merge in its XCD's L2 before they reach HBM.
+// 64-lane accesses with all loads of a tile issued before the first use, digit ranking goes
+// through per-wave LDS tables, and each workgroup owns a contiguous chunk of rows so that the
+// runs it appends to a digit bin are adjacent in memory and merge in its XCD's L2.
 #include "common.hpp"
 
 namespace sebm25 {
@@ -14,18 +14,8 @@ namespace sebm25 {
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Lanes of the wave that hold the same `bits`-bit digit as this lane (only among `valid`).
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, int bits, bool valid) {
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-        const bool one = (d >> b) & 1u;
-        const uint64_t bal = __ballot(one);
-        peers &= one ? bal : ~bal;
-    }
-    return peers;
-}
-
-// The same set, found through LDS instead of one ballot per digit bit.  The group of the first
+// Lanes of the wave that hold the same `bits`-bit digit as this lane (only among `valid`), found
+// through LDS instead of one ballot per digit bit.  The group of the first
 // valid lane (the hot digit of a skewed or sorted round) is taken by one compare; every other
 // lane ORs its lane bit into a per-wave table slot chosen by the low MATCH_TAB_BITS digit bits,
 // reads the slot back (all lanes that share those bits), and the remaining high bits are settled
@@ -116,7 +106,7 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid)
 template <int MODE>
 __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const uint64_t* packed, uint64_t R,
                                                             uint64_t chunk_rows, uint32_t G, int shift, int bits,
-                                                            RowFmt fmt, uint32_t* chunk_hist) {
+                                                            RowFmt fmt, uint32_t n_terms, uint32_t* chunk_hist) {
     __shared__ uint32_t hist[SORT_MAX_BINS];
     const uint32_t nb = 1u << bits, mask = nb - 1u;
     for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) hist[d] = 0;
@@ -139,14 +129,15 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
 #pragma unroll
             for (int u = 0; u < HIST_UNROLL; ++u) {
                 const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
-                hist_add(hist, (x[u].x >> sh) & mask, ok);
-                hist_add(hist, (x[u].y >> sh) & mask, ok);
-                hist_add(hist, (x[u].z >> sh) & mask, ok);
-                hist_add(hist, (x[u].w >> sh) & mask, ok);
+                // term ids are clamped exactly as the scatter clamps them, so both agree on every digit
+                hist_add(hist, (min(x[u].x, n_terms - 1u) >> sh) & mask, ok);
+                hist_add(hist, (min(x[u].y, n_terms - 1u) >> sh) & mask, ok);
+                hist_add(hist, (min(x[u].z, n_terms - 1u) >> sh) & mask, ok);
+                hist_add(hist, (min(x[u].w, n_terms - 1u) >> sh) & mask, ok);
             }
         }
         for (uint64_t i = begin + nvec * 4 + threadIdx.x; i < end; i += HIST_THREADS)
-            atomicAdd(&hist[(raw.term[i] >> sh) & mask], 1u);
+            atomicAdd(&hist[(min(raw.term[i], n_terms - 1u) >> sh) & mask], 1u);
     } else if (MODE == 2) {
         const ulonglong2* p = reinterpret_cast<const ulonglong2*>(packed + begin);
         const uint64_t nvec = n / 2;
@@ -169,7 +160,8 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
     } else {
         for (uint64_t i = begin + threadIdx.x; i < end; i += HIST_THREADS) {
             const uint32_t m = raw.meta[i];
-            const uint64_t key = fmt.pack(raw.term[i], ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u, raw.unit[i], 0u, 0ull);
+            const uint64_t key = fmt.pack(min(raw.term[i], n_terms - 1u), ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u,
+                                          raw.unit[i] & (uint32_t)((1ull << fmt.unit_bits) - 1ull), 0u, 0ull);
             atomicAdd(&hist[(uint32_t)(key >> shift) & mask], 1u);
         }
     }
@@ -178,97 +170,111 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
 }
 
 // ------------------------------------------------------------------ scatter (downsweep) ---
-// Exclusive scan over `n` (<= 2 * SORT_THREADS) LDS words, two consecutive words per thread.
-__device__ __forceinline__ void block_exclusive_scan_1024(uint32_t* v, uint32_t n, uint32_t* wave_tot) {
-    const uint32_t t = threadIdx.x;
-    const uint32_t a = (2 * t < n) ? v[2 * t] : 0u;
-    const uint32_t b = (2 * t + 1 < n) ? v[2 * t + 1] : 0u;
-    uint32_t inc = a + b;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t x = __shfl_up(inc, off);
-        if ((int)lane_id() >= off) inc += x;
-    }
-    if (lane_id() == 63) wave_tot[t >> 6] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < (t >> 6); ++w) base += wave_tot[w];
-    const uint32_t excl = base + inc - (a + b);
-    if (2 * t < n) v[2 * t] = excl;
-    if (2 * t + 1 < n) v[2 * t + 1] = excl + a;
-    __syncthreads();
-}
+#ifdef SEBM25_PHASE_STAMPS
+// Diagnostic build only: per-workgroup cycle totals of each tile phase of the scatter kernels.
+__device__ unsigned long long g_stamps[3][1024][8];
+#define STAMP(k)                                                                  \
+    do {                                                                          \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();            \
+        if (threadIdx.x == 0) g_stamps[MODE][blockIdx.x & 1023][k] += now__ - t_prev; \
+        t_prev = now__;                                                           \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-length counters
 
-// MODE 1: raw rows in (validated, packed, body lengths accumulated); MODE 2: packed rows in.
+// MODE 0: raw rows, digit inside the term bits (unit-major input: the usual first pass)
+// MODE 1: raw rows, digit anywhere in the packed key (first pass of a (term, source, unit) sort)
+// MODE 2: packed rows
+// Raw rows are validated, packed and their body lengths accumulated on the way through.
+//
+// The tile loop is software-pipelined around the vector-memory counter, which retires loads and
+// stores in issue order: the loads of the NEXT tile are issued after the current tile has been
+// reordered in LDS (its registers are free then) and BEFORE its stores, and both the loads and
+// the stores of a tile are unconditional and fixed in number (rows past the end read a clamped
+// address and write a dump word).  The wait at the top of the next tile can therefore leave the
+// stores in flight instead of draining them.
 template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                uint64_t R, uint64_t chunk_rows, uint32_t G, int shift,
                                                                int bits, BuildCtx ctx, const uint32_t* chunk_off) {
-    __shared__ unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then per-wave offsets
-    __shared__ uint32_t mtab[SORT_WAVES][2 << MATCH_TAB_BITS];     // per wave: lane masks per folded digit
-    __shared__ uint64_t rows_s[SORT_TILE];                 // the tile, locally ordered by digit
-    __shared__ uint32_t tile_start[SORT_MAX_BINS];         // first local slot of each digit
-    __shared__ uint32_t bin_base[SORT_MAX_BINS];           // next global slot of each digit for this chunk
+    __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
+    __shared__ uint32_t mtab[SORT_WAVES][2 << MATCH_TAB_BITS];  // per wave: lane masks per folded digit
+    __shared__ uint64_t rows_s[SORT_TILE];                      // the tile, locally ordered by digit
+    __shared__ uint32_t delta[SORT_MAX_BINS];     // global slot minus local slot, per digit, this tile
+    __shared__ uint32_t bin_base[SORT_MAX_BINS];  // next global slot of each digit for this chunk
     __shared__ uint32_t wave_tot[SORT_WAVES];
-    __shared__ uint32_t dl_s[DL_SPAN];                     // body length per doc of this tile
+    __shared__ uint32_t dl_s[DL_SPAN];            // body length per doc of this tile
 
     const RowFmt fmt = ctx.fmt;
     const uint32_t nb = 1u << bits, mask = nb - 1u;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
+    const uint32_t t = threadIdx.x;
+    // workgroups b, b + 8, b + 16 ... run on one XCD: give them consecutive chunks, so that the runs
+    // they append to a digit bin at about the same time are neighbours in that XCD's L2
+    const uint32_t per_xcd = (G + 7u) / 8u;
+    const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (chunk >= G) return;
+    const uint64_t begin = (uint64_t)chunk * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
-    for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) bin_base[d] = chunk_off[(size_t)d * G + blockIdx.x];
-    for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
-    for (uint32_t x = threadIdx.x; x < SORT_WAVES * (2u << MATCH_TAB_BITS); x += SORT_THREADS) (&mtab[0][0])[x] = 0;
-    if (MODE != 2) dl_s[threadIdx.x] = 0;
+    if (begin >= end) return;
+    uint32_t* wh32 = reinterpret_cast<uint32_t*>(&whist[0][0]);  // two 16-bit counters per word
+    for (uint32_t d = t; d < nb; d += SORT_THREADS) bin_base[d] = chunk_off[(size_t)d * G + chunk];
+    for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
+    for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS); x += SORT_THREADS) (&mtab[0][0])[x] = 0;
+    if (MODE != 2) dl_s[t] = 0;
     __syncthreads();
 
-    // All loads of a tile are issued before the first use (the other workgroup on the CU covers
-    // their latency; loading a tile ahead was measured and bought nothing).
     uint64_t row[SORT_ITEMS];
-    uint32_t term[SORT_ITEMS], unit[SORT_ITEMS], tfv[SORT_ITEMS], m[SORT_ITEMS];
-    uint64_t carry_in = 0;   // (source, unit) of the row before this wave's first row
-    uint32_t u_first = 0;    // first doc of the tile
-    bool tile_web = false;
+    uint32_t term[SORT_ITEMS], unit[SORT_ITEMS], tfv[SORT_ITEMS], m[SORT_ITEMS];  // raw columns (MODE 0, 1)
+    uint32_t prev_u = 0, prev_m = 0, first_u = 0, first_m = 0;  // row before this wave's rows; first row of the tile
+    // wave w owns rows [tile + w*64*ITEMS, +64*ITEMS) of a tile, 64 consecutive rows per round
     auto load_tile = [&](uint64_t t0) {
         const uint64_t w0 = t0 + (uint64_t)wave * 64u * SORT_ITEMS;
-        if (MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) {
-                const uint64_t i = w0 + (uint64_t)j * 64u + lane;
-                row[j] = i < end ? packed[i] : ~0ull;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) {
-                const uint64_t i = w0 + (uint64_t)j * 64u + lane;
-                const bool valid = i < end;
-                term[j] = valid ? raw.term[i] : 0u;
-                unit[j] = valid ? raw.unit[i] : 0u;
-                tfv[j] = valid ? raw.tf[i] : 0u;
-                m[j] = valid ? raw.meta[i] : (uint32_t)SEBM25_SRC_WEB;
-            }
-            carry_in = 0;
-            if (w0 > 0 && w0 < end) {
-                const uint32_t pm = raw.meta[w0 - 1];
-                carry_in = ((uint64_t)(((pm & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | raw.unit[w0 - 1];
-            }
-            if (t0 < end) {
-                u_first = raw.unit[t0];
-                tile_web = (raw.meta[t0] & 3u) == SEBM25_SRC_WEB;
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const uint64_t i = min(w0 + (uint64_t)j * 64u + lane, end - 1);
+            if (MODE == 2) {
+                row[j] = packed[i];
+            } else {
+                term[j] = raw.term[i];
+                unit[j] = raw.unit[i];
+                tfv[j] = raw.tf[i];
+                m[j] = raw.meta[i];
             }
         }
-    };
-    for (uint64_t tile0 = begin; tile0 < end; tile0 += SORT_TILE) {
-        load_tile(tile0);
-        // wave w owns rows [tile0 + w*64*ITEMS, +64*ITEMS), 64 consecutive rows per round
-        const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;
-        const uint32_t tile_u_first = u_first;
         if (MODE != 2) {
-            uint64_t carry = carry_in;
-            const bool t_web = tile_web;
+            const uint64_t ip = min(w0 ? w0 - 1 : 0, end - 1), i0 = min(t0, end - 1);
+            prev_u = raw.unit[ip];
+            prev_m = raw.meta[ip];
+            first_u = raw.unit[i0];
+            first_m = raw.meta[i0];
+        }
+    };
+    load_tile(begin);
+    // as many stores behind the first tile's loads as behind every later tile's
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) ctx.dump[j * 64 + lane] = 0ull;
+#ifdef SEBM25_PHASE_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (uint64_t tile0 = begin; tile0 < end; tile0 += SORT_TILE) {
+        const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;
+        uint32_t tile_u_first = 0;
+        bool tile_web = false;
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j)
+                if (wave0 + (uint64_t)j * 64u + lane >= end) row[j] = ~0ull;
+        } else {
+            // validate and pack the raw rows, check unit-major order, accumulate body lengths
+            tile_u_first = first_u;
+            tile_web = (first_m & 3u) == SEBM25_SRC_WEB;
+            // (source, unit) of the row before this wave's first row
+            uint64_t carry = wave0 > 0 ? (((uint64_t)(((prev_m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | prev_u) : 0ull;
 #pragma unroll
             for (int j = 0; j < SORT_ITEMS; ++j) {
                 const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
@@ -277,13 +283,14 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
                 const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
                 uint64_t r = ~0ull;
                 if (valid) {
-                    const bool bad = !(ctx.debug & 2u) && (term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
+                    const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
                                      unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
-                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u));
+                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
                     if (bad) {
                         atomicOr(ctx.err, DEV_ERR_RANGE);
-                        term[j] = min(term[j], ctx.n_terms - 1u);  // keep every later index in range
-                        unit[j] = 0;
+                        // the same key bits as the histogram saw, every later index in range
+                        term[j] = min(term[j], ctx.n_terms - 1u);
+                        unit[j] &= (uint32_t)((1ull << fmt.unit_bits) - 1ull);
                         tfv[j] = 0;
                     }
                     r = fmt.pack(term[j], src, unit[j], field_code(field), tfv[j]);
@@ -308,13 +315,14 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
                 }
                 if (do_add) {
                     const uint32_t off = unit[j] - tile_u_first;
-                    if (t_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
+                    if (tile_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
                         atomicAdd(&dl_s[off], add);
                     else
                         atomicAdd(&ctx.doc_len[unit[j]], add);
                 }
             }
         }
+        STAMP(0);  // rows available and packed
 
         // ---- rank: position of each row among the rows of its digit held by this wave
         uint32_t rk[SORT_ITEMS];
@@ -324,38 +332,71 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
             const bool valid = i < end;
             const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
             const uint64_t peers = match_digit_lds(mtab[wave], d, bits, valid);
-            const int leader = __ffsll((unsigned long long)peers) - 1;
+            // every lane of a digit group reads the group's running count (one address: a broadcast),
+            // then its first lane adds the group's size
             uint32_t old = 0;
-            if (valid && (int)lane == leader) {
-                old = whist[wave][d];
-                whist[wave][d] = (unsigned short)(old + (uint32_t)__popcll(peers));
-            }
-            old = __shfl(old, leader < 0 ? 0 : leader);
+            if (valid) old = whist[wave][d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lanemask_lt()) == 0) whist[wave][d] = (unsigned short)(old + (uint32_t)__popcll(peers));
             rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
             __builtin_amdgcn_wave_barrier();
         }
+        STAMP(1);  // ranked
         __syncthreads();
+        STAMP(2);  // barrier
 
-        // ---- per digit: exclusive offsets over the waves, tile count; flush body lengths
-        for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) {
-            uint32_t run = 0;
+        // ---- per digit pair (2t, 2t+1): exclusive offsets over the waves and the tile counts, two
+        //      16-bit counters per LDS word; then a block scan of the counts held in registers
+        uint32_t c0 = 0, c1 = 0;
+        if (2 * t < nb) {
+            uint32_t c[SORT_WAVES];
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
+            uint32_t run = 0;  // packed: neither half can carry (a tile has at most 4096 rows)
 #pragma unroll
             for (int w = 0; w < SORT_WAVES; ++w) {
-                const uint32_t c = whist[w][d];
-                whist[w][d] = (unsigned short)run;
-                run += c;
+                const uint32_t x = c[w];
+                c[w] = run;
+                run += x;
             }
-            tile_start[d] = run;
+            c0 = run & 0xFFFFu;
+            c1 = run >> 16;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w];
         }
         if (MODE != 2) {
-            const uint32_t v = dl_s[threadIdx.x];
+            const uint32_t v = dl_s[t];
             if (v) {
-                atomicAdd(&ctx.doc_len[tile_u_first + threadIdx.x], v);
-                dl_s[threadIdx.x] = 0;
+                atomicAdd(&ctx.doc_len[tile_u_first + t], v);
+                dl_s[t] = 0;
             }
         }
+        uint32_t inc = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += x;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
-        block_exclusive_scan_1024(tile_start, nb, wave_tot);
+        if (2 * t < nb) {
+            uint32_t ts0 = inc - (c0 + c1);
+            for (uint32_t w = 0; w < wave; ++w) ts0 += wave_tot[w];
+            const uint32_t ts1 = ts0 + c0;
+            // global slot of local slot p of digit d: delta[d] + p (32-bit wrap-around arithmetic)
+            delta[2 * t] = bin_base[2 * t] - ts0;
+            bin_base[2 * t] += c0;
+            delta[2 * t + 1] = bin_base[2 * t + 1] - ts1;
+            bin_base[2 * t + 1] += c1;
+            const uint32_t add = ts0 | (ts1 << 16);  // per-wave offsets become local slots
+            uint32_t c[SORT_WAVES];
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w] + add;
+        }
+        __syncthreads();
+        STAMP(3);  // offsets
 
         // ---- reorder the tile by digit inside LDS (stable)
         const uint32_t n_tile = (uint32_t)min((uint64_t)SORT_TILE, end - tile0);
@@ -364,25 +405,29 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
             const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
             if (i < end) {
                 const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
-                rows_s[tile_start[d] + whist[wave][d] + rk[j]] = row[j];
+                rows_s[whist[wave][d] + rk[j]] = row[j];
             }
         }
+        load_tile(tile0 + SORT_TILE);  // next tile (clamped addresses behind the chunk's end)
         __syncthreads();
+        STAMP(4);  // reordered
 
         // ---- write out: consecutive threads hold consecutive slots of a digit's run
-        for (uint32_t p = threadIdx.x; p < n_tile; p += SORT_THREADS) {
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const uint32_t p = t + (uint32_t)j * SORT_THREADS;
             const uint64_t r = rows_s[p];
             const uint32_t d = (uint32_t)(r >> shift) & mask;
-            dst[(uint64_t)bin_base[d] + (p - tile_start[d])] = r;
+            uint64_t* out = p < n_tile ? dst + (uint32_t)(delta[d] + p) : ctx.dump + lane;
+            *out = r;
         }
-        for (uint32_t x = threadIdx.x; x < SORT_WAVES * nb; x += SORT_THREADS) whist[x / nb][x % nb] = 0;
+        {
+            uint4* z = reinterpret_cast<uint4*>(&whist[0][0]);
+            for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS * 2 / 16; x += SORT_THREADS) z[x] = make_uint4(0, 0, 0, 0);
+        }
+        STAMP(5);  // stores issued
         __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nb; d += SORT_THREADS) {
-            const uint32_t nxt = (d + 1 < nb) ? tile_start[d + 1] : n_tile;
-            bin_base[d] += nxt - tile_start[d];
-        }
-        // bin_base is next read after the following tile's barriers; tile_start is next written
-        // after the barrier that ends its rank phase
+        STAMP(6);  // tile end barrier
     }
 }
 
@@ -390,21 +435,23 @@ void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R,
                       int shift, int bits, const BuildCtx& ctx, uint32_t* chunk_hist, hipStream_t st) {
     dim3 grid(G), block(HIST_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_hist<1>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<1>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
     else
-        hipLaunchKernelGGL(k_sort_hist<2>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<2>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
 }
 
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
                          uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
                          const uint32_t* chunk_off, hipStream_t st) {
-    dim3 grid(G), block(SORT_THREADS);
-    if (mode == 2)
-        hipLaunchKernelGGL(k_sort_scatter<2>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
-    else  // raw rows are always fully packed by the scatter, whatever the digit source
+    dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_sort_scatter<0>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
+    else if (mode == 1)
         hipLaunchKernelGGL(k_sort_scatter<1>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
+    else
+        hipLaunchKernelGGL(k_sort_scatter<2>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------
@@ -778,3 +825,14 @@ void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_t
 }
 
 }  // namespace sebm25
+
+#ifdef SEBM25_PHASE_STAMPS
+extern "C" int sebm25_debug_stamps(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sebm25::g_stamps), sizeof(sebm25::g_stamps)) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zero[3][1024][8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sebm25::g_stamps), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

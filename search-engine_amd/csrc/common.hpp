@@ -96,6 +96,8 @@ constexpr int RED_THREADS = 256;
 constexpr int RED_ROUNDS = 8;                 // 64-row rounds a wave loads before it processes them
 constexpr int RED_BATCH = 64 * RED_ROUNDS;
 
+constexpr int DUMP_WORDS = 64 * SORT_ITEMS;
+
 struct BuildCtx {
     RowFmt fmt;
     uint32_t n_terms, n_docs, n_articles;
@@ -103,6 +105,7 @@ struct BuildCtx {
     uint32_t debug;         // experiment switches (SEBM25_DEBUG): 1 skip body lengths, 2 skip validation
     uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
     uint32_t* err;          // device error word
+    uint64_t* dump;         // DUMP_WORDS words that absorb the stores of rows behind the end
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsebm25.so")
+LIB_PATH = os.environ.get("SEBM25_LIB") or os.path.join(_HERE, "lib", "libsebm25.so")
 
 SRC_WEB, SRC_NEWS = 1, 2
 FIELD_TITLE, FIELD_DESCRIPTION, FIELD_BODY = 1, 2, 4
