@@ -74,7 +74,7 @@ typedef struct sebm25_rows {
     const uint32_t* unit_id;    /* [n_rows] doc id (web rows) or article index (news rows)       */
     const uint32_t* tf;         /* [n_rows] tokens.frequency                                     */
     const uint8_t* meta;        /* [n_rows] SEBM25_META(source_type, field)                      */
-    uint64_t n_rows;            /* R, at most 2^32 - 2                                           */
+    uint64_t n_rows;            /* R, at most 2^32 - 4096                                        */
     uint32_t n_terms;           /* V >= 1                                                        */
     uint32_t n_docs;            /* size of the web doc id space (rows of `documents`)            */
     uint32_t n_articles;        /* size of the news article index space                          */

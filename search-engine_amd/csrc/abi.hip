@@ -32,15 +32,15 @@ struct sebm25_index {
     uint32_t n_pass = 0;
     int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
     int score_window = 1024;        // unit ids per scoring window (tuning knob: SEBM25_SCORE_WINDOW = 1024 | 2048)
-    uint64_t P = 0, WH = 0;
+    uint64_t P = 0, P_web = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
     sebm25_doc_totals local_totals{}, used_totals{};
     uint64_t N = 1;
     double avgdl = 0.0;
 
-    DevBuf sortA, sortB, chunk_hist, scan_tmp, chunk_counts;
-    DevBuf row_ptr, news_ptr, wh_ptr, rs_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
-    DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc; u32 err at [7]
+    DevBuf sortA, sortB, chunk_hist, scan_tmp;
+    DevBuf row_ptr, news_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
+    DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc, 5 kept web postings; u32 err at [7]; then the dump words
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
     DevBuf url_rank_web, url_rank_news;
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
@@ -195,7 +195,7 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
 int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
     if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
-    if (in->n_rows > 0xFFFFFFFEull) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 2 rows in one shard");
+    if (in->n_rows > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
     if (in->n_rows && (!in->term_id || !in->unit_id || !in->tf || !in->meta))
         return fail(ix, SEBM25_E_INVALID, "build: a row array is NULL");
     if (in->flags & ~SEBM25_ROWS_UNIT_MAJOR) return fail(ix, SEBM25_E_INVALID, "build: unknown flag");
@@ -215,12 +215,11 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
 
     // ---- device memory
     const size_t Rcap = std::max<uint64_t>(R, 1);
-    HIP_TRY(ix, ix->sortA.ensure(Rcap * 8));
-    HIP_TRY(ix, ix->sortB.ensure(Rcap * 8));
+    // each sort buffer later holds the two posting slot arrays, padded by POST_PAD entries each
+    HIP_TRY(ix, ix->sortA.ensure((Rcap + POST_PAD) * 8));
+    HIP_TRY(ix, ix->sortB.ensure((Rcap + POST_PAD) * 8));
     HIP_TRY(ix, ix->row_ptr.ensure(((size_t)V + 1) * 4));
     HIP_TRY(ix, ix->news_ptr.ensure((size_t)V * 4));
-    HIP_TRY(ix, ix->wh_ptr.ensure(((size_t)V + 1) * 4));
-    HIP_TRY(ix, ix->rs_ptr.ensure(((size_t)V + 1) * 4));
     HIP_TRY(ix, ix->df_local.ensure((size_t)V * 4));
     HIP_TRY(ix, ix->term_rows.ensure((size_t)V * 4));
     HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
@@ -246,6 +245,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
 
     uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
     uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
+    const uint64_t* sorted_rows = nullptr;
 
     if (R == 0) {
         HIP_TRY(ix, hipMemsetAsync(row_ptr, 0, ((size_t)V + 1) * 4, ix->stream));
@@ -307,34 +307,27 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         }
         HIP_TRY(ix, hipGetLastError());
         const uint64_t* sorted = src_packed;
+        sorted_rows = sorted;
         uint64_t* other = bufs[n_pass & 1];  // the buffer the last pass did not write
         // postings live in the free sort buffer: unit ids in its first half, weights in the second
         ix->post_unit = reinterpret_cast<uint32_t*>(other);
-        ix->post_w = reinterpret_cast<uint32_t*>(other) + Rcap;
+        ix->post_w = reinterpret_cast<uint32_t*>(other) + Rcap + POST_PAD;
 
-        // ---- segmented reduction into postings: one contiguous range of rows per wavefront
+        // ---- postings, one slot per sorted row: one contiguous range of rows per wavefront
         uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
         chunk2 = (chunk2 + RED_BATCH - 1) / RED_BATCH * RED_BATCH;
         const uint32_t n_chunks = (uint32_t)((R + chunk2 - 1) / chunk2);
-        HIP_TRY(ix, ix->chunk_counts.ensure((size_t)2 * (n_chunks + 1) * 4));
-        uint32_t* cnt_kept = ix->chunk_counts.as<uint32_t>();
-        uint32_t* cnt_wh = cnt_kept + (n_chunks + 1);
-        HIP_TRY(ix, hipMemsetAsync(cnt_kept, 0, (size_t)2 * (n_chunks + 1) * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
-        phase_begin(ix, "reduce_count");
-        launch_reduce_count(sorted, R, chunk2, n_chunks, fmt, flags_dev, cnt_kept, cnt_wh, ix->stream);
-        phase_end(ix);
-        phase_begin(ix, "reduce_scan");
-        launch_exclusive_scan_u32(cnt_kept, n_chunks + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
-        launch_exclusive_scan_u32(cnt_wh, n_chunks + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
-        phase_end(ix);
-        phase_begin(ix, "reduce_emit");
-        launch_reduce_emit(sorted, R, chunk2, n_chunks, fmt, flags_dev, cnt_kept, cnt_wh, V, ix->post_unit, ix->post_w,
-                           row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(), scal, err_dev, ix->stream);
+        HIP_TRY(ix, hipMemsetAsync(row_ptr, 0xFF, ((size_t)V + 1) * 4, ix->stream));
+        HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
+        HIP_TRY(ix, ix->scan_tmp.ensure(row_ptr_fill_tmp_words(V) * 4));
+        phase_begin(ix, "postings");
+        launch_postings(sorted, R, chunk2, n_chunks, fmt, flags_dev, in->n_docs, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
+                        ix->df_local.as<uint32_t>(), scal, err_dev, ix->stream);
         phase_end(ix);
         phase_begin(ix, "term_stats");
-        launch_term_stats(V, row_ptr, news_ptr, ix->wh_ptr.as<uint32_t>(), ix->rs_ptr.as<uint32_t>(),
-                          ix->df_local.as<uint32_t>(), ix->term_rows.as<uint32_t>(), ix->stream);
+        launch_row_ptr_fill(row_ptr, V, R, ix->scan_tmp.as<uint32_t>(), ix->stream);
+        launch_term_stats(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->stream);
         phase_end(ix);
     }
     phase_begin(ix, "doc_stats");
@@ -345,14 +338,23 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     uint64_t h[8];
     HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
-    const uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    if ((dev_err & DEV_NEED_FIXUP) && !(dev_err & (DEV_ERR_RANGE | DEV_ERR_ORDER))) {
+        // rare runs the streaming kernel leaves to an exact second look
+        launch_postings_fixup(sorted_rows, R, fmt, ix->post_w, err_dev, ix->stream);
+        HIP_TRY(ix, hipGetLastError());
+        HIP_TRY(ix, hipMemcpyAsync(h + 7, scal + 7, 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+        dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    }
     if (dev_err & DEV_ERR_RANGE)
         return fail(ix, SEBM25_E_RANGE, "build: a row has term_id >= n_terms, a unit id outside its id space, an invalid "
-                                        "source_type, a tf too wide for the packed row, or a posting weight above 2^32 - 1 tenths");
+                                        "source_type, a tf too wide for the packed row, or a posting weight above 2^32 - 2 tenths");
     if (dev_err & DEV_ERR_ORDER)
         return fail(ix, SEBM25_E_ORDER, "build: rows were declared unit-major (SEBM25_ROWS_UNIT_MAJOR) but are not");
     ix->P = h[0];
     ix->WH = h[1];
+    ix->P_web = h[5];
     ix->local_totals.n_done = h[2];
     ix->local_totals.n_wc = h[3];
     ix->local_totals.sum_wc = h[4];
@@ -392,8 +394,8 @@ void sebm25_destroy(sebm25_index* ix) {
     {
         DeviceGuard g(ix->device);
         (void)hipStreamSynchronize(ix->stream);
-        DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->scan_tmp, &ix->chunk_counts, &ix->row_ptr, &ix->news_ptr,
-                         &ix->wh_ptr, &ix->rs_ptr, &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
+        DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->scan_tmp, &ix->row_ptr, &ix->news_ptr,
+                         &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
                          &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
                          &ix->st_flags, &ix->st_misc, &ix->url_rank_web, &ix->url_rank_news, &ix->q_items, &ix->q_terms,
                          &ix->q_first, &ix->q_n, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
@@ -548,13 +550,9 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_info: no index built on this handle");
-    int rc = refresh_host_ptrs(ix);
-    if (rc) return rc;
-    uint64_t web = 0;
-    for (uint32_t t = 0; t < ix->V; ++t) web += ix->h_news_ptr[t] - ix->h_row_ptr[t];
     out->n_rows = ix->R;
     out->n_postings = ix->P;
-    out->n_web_postings = web;
+    out->n_web_postings = ix->P_web;
     out->n_terms = ix->V;
     out->n_docs = ix->n_docs;
     out->n_articles = ix->n_articles;
@@ -573,18 +571,42 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_postings: no index built on this handle");
     int rc = refresh_host_ptrs(ix);
     if (rc) return rc;
-    // row pointers are widened on the host (the ABI promises 64-bit offsets)
-    if (row_ptr) {
-        if (is_device_ptr(row_ptr)) return fail(ix, SEBM25_E_INVALID, "get_postings: row_ptr must be a host array");
-        for (size_t t = 0; t <= ix->V; ++t) row_ptr[t] = ix->h_row_ptr[t];
+    if ((row_ptr && is_device_ptr(row_ptr)) || (news_ptr && is_device_ptr(news_ptr)))
+        return fail(ix, SEBM25_E_INVALID, "get_postings: row_ptr and news_ptr must be host arrays");
+    // The index keeps one slot per sorted row (holes where rows were merged or filtered); this
+    // export compacts it on the host into the CSR the ABI describes.
+    const size_t R = ix->R;
+    std::vector<uint32_t> su(R), sw(R);
+    if (R) {
+        HIP_TRY(ix, hipMemcpyAsync(su.data(), ix->post_unit, R * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipMemcpyAsync(sw.data(), ix->post_w, R * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     }
-    if (news_ptr) {
-        if (is_device_ptr(news_ptr)) return fail(ix, SEBM25_E_INVALID, "get_postings: news_ptr must be a host array");
-        for (size_t t = 0; t < ix->V; ++t) news_ptr[t] = ix->h_news_ptr[t];
+    const bool want_posts = post_unit || post_weight;
+    std::vector<uint32_t> cu, cw;
+    if (want_posts) {
+        cu.reserve(ix->P);
+        cw.reserve(ix->P);
     }
-    if ((rc = copy_out(ix, post_unit, ix->post_unit, (size_t)ix->P * 4))) return rc;
-    if ((rc = copy_out(ix, post_weight, ix->post_w, (size_t)ix->P * 4))) return rc;
-    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    uint64_t n = 0;
+    for (size_t t = 0; t < ix->V; ++t) {
+        if (row_ptr) row_ptr[t] = n;
+        const uint32_t b = ix->h_row_ptr[t], m = ix->h_news_ptr[t], e = ix->h_row_ptr[t + 1];
+        for (uint32_t i = b; i < e; ++i) {
+            if (i == m && news_ptr) news_ptr[t] = n;
+            if (sw[i] == POST_HOLE) continue;
+            if (want_posts) {
+                cu.push_back(su[i]);
+                cw.push_back(sw[i]);
+            }
+            ++n;
+        }
+        if (m == e && news_ptr) news_ptr[t] = n;
+    }
+    if (row_ptr) row_ptr[ix->V] = n;
+    if (n != ix->P) return fail(ix, SEBM25_E_INTERNAL, "get_postings: slot array and posting count disagree");
+    if (post_unit && n) HIP_TRY(ix, hipMemcpy(post_unit, cu.data(), n * 4, hipMemcpyDefault));
+    if (post_weight && n) HIP_TRY(ix, hipMemcpy(post_weight, cw.data(), n * 4, hipMemcpyDefault));
     return SEBM25_OK;
 }
 

@@ -551,208 +551,343 @@ void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStrea
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st, data, n, tmp);
 }
 
-// ------------------------------------------------------------------ segmented reduction ---
-// Sorted rows -> one posting per (term, source, unit).  Each wavefront streams its own
-// contiguous range of rows (no workgroup barriers): 64 consecutive rows per load, neighbours
-// compared through lane shuffles, output slots from ballot prefix counts, so posting stores
-// are coalesced.  Flags per row:
+// ------------------------------------------------------------------ postings ----------------
+// Sorted rows -> postings, one slot per sorted row and in the same place: slot i holds the unit
+// of row i and, when row i is the first row of a kept (term, source, unit) run, the run's
+// weight; every other slot is a hole (POST_HOLE) that scoring skips.  Nothing has to be counted
+// or prefix-summed first, so the rows are read once.  Each wavefront streams its own contiguous
+// range of rows (no workgroup barriers): 64 consecutive rows per load, neighbours compared
+// through lane shifts, coalesced slot stores.
+// 32-bit views of the packed row's fields.  The 64-bit shifts and compares of RowFmt cost
+// several times a 32-bit operation; here every test is a mask on one or both halves of the row
+// and every extraction a funnel shift.  All members are wave-uniform.
+struct RowBits {
+    uint32_t key_hi, key_lo;  // (term, source, unit) bits
+    uint32_t term_hi;         // term bits: always inside the high word (term ids are 32-bit)
+    uint32_t src_hi, src_lo;  // the source bit
+    uint32_t big_hi, big_lo;  // tf bits from 2^24 up
+    uint32_t unit_mask, tf24_mask;
+    int term_sh, unit_sh, fc_sh;
+    __device__ explicit RowBits(const RowFmt& f) {
+        const uint64_t key = ~0ull << f.key_shift(), src = 1ull << f.src_shift();
+        const uint64_t tf = (1ull << f.tf_bits) - 1ull, big = tf & ~0xFFFFFFull;
+        key_hi = (uint32_t)(key >> 32); key_lo = (uint32_t)key;
+        term_hi = (uint32_t)((~0ull << f.term_shift()) >> 32);
+        src_hi = (uint32_t)(src >> 32); src_lo = (uint32_t)src;
+        big_hi = (uint32_t)(big >> 32); big_lo = (uint32_t)big;
+        unit_mask = (uint32_t)((1ull << f.unit_bits) - 1ull);
+        tf24_mask = (uint32_t)(tf & 0xFFFFFFull);
+        term_sh = f.term_shift() - 32; unit_sh = f.unit_shift(); fc_sh = f.tf_bits;
+    }
+};
+__device__ __forceinline__ uint32_t hi32(uint64_t r) { return (uint32_t)(r >> 32); }
+__device__ __forceinline__ uint32_t lo32(uint64_t r) { return (uint32_t)r; }
+// low 32 bits of (r >> sh), sh wave-uniform
+__device__ __forceinline__ uint32_t shr_lo32(uint64_t r, int sh) {
+    const uint32_t a = __builtin_amdgcn_alignbit(hi32(r), lo32(r), (uint32_t)sh & 31u);
+    const uint32_t b = hi32(r) >> ((uint32_t)sh & 31u);
+    return sh < 32 ? a : b;
+}
+__device__ __forceinline__ bool key_differs(const RowBits& b, uint64_t x, uint64_t y) {
+    return (((hi32(x) ^ hi32(y)) & b.key_hi) | ((lo32(x) ^ lo32(y)) & b.key_lo)) != 0u;
+}
+__device__ __forceinline__ bool is_news(const RowBits& b, uint64_t r) {
+    return ((hi32(r) & b.src_hi) | (lo32(r) & b.src_lo)) != 0u;
+}
+__device__ __forceinline__ bool tf_big(const RowBits& b, uint64_t r) {
+    return ((hi32(r) & b.big_hi) | (lo32(r) & b.big_lo)) != 0u;
+}
+// weight of one row in tenths, tf < 2^24: web tf * {32, 17, 10}[field code] (W = 3.2 / 1.7 / 1.0,
+// search_service.py:19-27), news 10 * tf (:84-87)
+__device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool news) {
+    const uint32_t fc = shr_lo32(r, b.fc_sh) & 3u;
+    const uint32_t mult = news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u);
+    return __umul24(lo32(r) & b.tf24_mask, mult);
+}
+
+// row_ptr[t] = first slot of term t (left at 0xFFFFFFFF for terms without rows), news_ptr[t] =
+// first news slot of term t (left at 0xFFFFFFFF for terms without news rows), df[t] += web heads of term t (zeroed by
+// the caller), totals[0] += kept postings, totals[1] += web heads, totals[5] += kept web postings.
+// Row flags:
 //   head    : first row of its (term, source, unit) run
 //   kept    : head of a news unit, or of a web doc whose status is 'done' (search_service.py:32)
 //   webhead : head of a web doc of any status -> counts toward df (bm25_stats.py:20)
-struct RowFlags {
-    bool head, kept, webhead;
-};
-__device__ __forceinline__ RowFlags row_flags(uint64_t r, uint64_t prev, bool first, bool valid, const RowFmt& f,
-                                              const uint8_t* doc_flags) {
-    RowFlags x;
-    x.head = valid && (first || f.key(r) != f.key(prev));
-    const bool news = f.src(r) != 0u;
-    x.webhead = x.head && !news;
-    x.kept = x.head && (news || !doc_flags || (doc_flags[f.unit(r)] & SEBM25_DOC_DONE));
-    return x;
-}
-
-__global__ __launch_bounds__(RED_THREADS) void k_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows,
-                                                              uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
-                                                              uint32_t* cnt_kept, uint32_t* cnt_wh) {
+//
+// Vector memory operations retire in issue order, so waiting for any load also waits for every
+// store issued before it.  The loop is therefore a three-stage pipeline in which loads are only
+// ever issued ahead of a batch's stores: while batch b is processed, the rows of batch b + 1 are
+// already in registers (their doc status bytes are gathered now) and the rows of batch b + 2 are
+// loaded.  Loads and slot stores are unconditional and fixed in number (clamped load addresses;
+// the slot arrays are padded by POST_PAD entries, which take the stores of lanes behind the last
+// row), which lets the wait at the end of a batch leave the batch's own stores in flight.
+//
+// Per row the kernel computes one 32-bit word v = tenths(row) | differs-from-predecessor << 31;
+// what a run head needs to know about the rows behind it (do they continue the run, what do they
+// weigh) then comes from three one-lane shifts of v instead of three more rows to decode.
+template <bool HAS_FLAGS>
+__global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, uint32_t R, uint32_t chunk_rows,
+                                                          uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
+                                                          uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit,
+                                                          uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
+                                                          uint32_t* df, unsigned long long* totals, uint32_t* err) {
     const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
+    const RowBits rb(fmt);
     const uint32_t lane = lane_id();
-    const uint64_t begin = (uint64_t)c * chunk_rows;
-    const uint64_t end = min(R, begin + chunk_rows);
-    uint64_t carry = begin ? rows[begin - 1] : 0ull;
-    uint32_t kept = 0, wh = 0;
-    for (uint64_t b0 = begin; b0 < end; b0 += 64u * RED_ROUNDS) {
-        uint64_t r[RED_ROUNDS];
+    const uint64_t lt = lanemask_lt();
+    const uint32_t begin = c * chunk_rows;  // host guarantees n_chunks * chunk_rows + 3 * RED_BATCH < 2^32
+    const uint32_t end = min(R, begin + chunk_rows);
+    const uint64_t key_lsb = 1ull << fmt.key_shift();
+    // rows behind the last one read as a row of another key; so does the row before row 0
+    const uint64_t behind = rows[R - 1] ^ key_lsb;
+    uint64_t carry = begin ? rows[begin - 1] : rows[0] ^ key_lsb;
+    uint32_t n_kept = 0, n_wh = 0, n_kept_web = 0;
+    // web heads of the term the last rounds consisted of, not yet added to df
+    constexpr uint32_t NO_TERM = 0xFFFFFFFFu;
+    uint32_t run_term = NO_TERM, run_wh = 0;
+
+    uint64_t ra[RED_ROUNDS], rb1[RED_ROUNDS], rc[RED_ROUNDS];  // rows of batch b, b + 1, b + 2
+    uint32_t da[RED_ROUNDS], db[RED_ROUNDS];                   // doc status of batch b, b + 1
+    auto load_rows = [&](uint32_t b0, uint64_t (&dst)[RED_ROUNDS]) {
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) dst[j] = rows[min(b0 + (uint32_t)j * 64u + lane, R - 1u)];
+    };
+    auto gather_flags = [&](const uint64_t (&src)[RED_ROUNDS], uint32_t (&dst)[RED_ROUNDS]) {
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
-            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
-            r[j] = i < end ? rows[i] : 0ull;
+            if (HAS_FLAGS)
+                dst[j] = doc_flags[min(shr_lo32(src[j], rb.unit_sh) & rb.unit_mask, n_docs - 1u)];
+            else
+                dst[j] = SEBM25_DOC_DONE;
+        }
+    };
+    // v of one round: needs the row before the round's first row
+    auto round_word = [&](uint64_t x, uint64_t before, bool news) -> uint32_t {
+        uint64_t prev = lane_up1(x);
+        if (lane == 0) prev = before;
+        return tenths24(rb, x, news) | (key_differs(rb, x, prev) ? 0x80000000u : 0u);
+    };
+    load_rows(begin, ra);
+    load_rows(begin + RED_BATCH, rb1);
+    gather_flags(ra, da);
+    // as many stores (into the padding) behind these loads as a batch issues behind its loads;
+    // the compiler must not move them ahead of the loads
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < RED_ROUNDS; ++j) {
+        post_unit[R + (uint32_t)j * 64u + lane] = 0u;
+        post_w[R + (uint32_t)j * 64u + lane] = POST_HOLE;
+    }
+    asm volatile("" ::: "memory");
+
+    for (uint32_t b0 = begin; b0 < end; b0 += RED_BATCH) {
+        gather_flags(rb1, db);
+        load_rows(b0 + 2 * RED_BATCH, rc);
+
+        // ---- phase 1: the word of every row of the batch, and of the first round behind it
+        uint32_t v[RED_ROUNDS + 1];
+        bool news[RED_ROUNDS];
+        uint64_t big = 0;
+        uint64_t before = carry;
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) {
+            if (b0 + (uint32_t)j * 64u + lane >= R) ra[j] = behind;
+            news[j] = is_news(rb, ra[j]);
+            v[j] = round_word(ra[j], before, news[j]);
+            big |= __ballot(tf_big(rb, ra[j]) && b0 + (uint32_t)j * 64u + lane < end);
+            before = lane_bcast<63>(ra[j]);
+        }
+        {
+            const uint64_t x = (b0 + RED_BATCH + lane >= R) ? behind : rb1[0];
+            v[RED_ROUNDS] = round_word(x, before, is_news(rb, x));
+        }
+        if (big && lane == 0) atomicOr(err, DEV_NEED_FIXUP);  // a tf of 2^24 or more: exact weights later
+
+        // ---- phase 2: slots, term boundaries, df
+#pragma unroll
+        for (int j = 0; j < RED_ROUNDS; ++j) {
+            const uint32_t i = b0 + (uint32_t)j * 64u + lane;
+            const bool valid = i < end;
+            const uint64_t vm = __ballot(valid);
+            const uint64_t x0 = ra[j];
+            // words of rows i+1 .. i+3: lane shifts; at the wave edge the first lanes of the next round
+            uint32_t n1 = lane_dn1(v[j]);
+            if (lane == 63) n1 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 0);
+            uint32_t n2 = lane_dn1(n1);
+            if (lane == 63) n2 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 1);
+            uint32_t n3 = lane_dn1(n2);
+            if (lane == 63) n3 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 2);
+
+            const bool head = valid && (v[j] >> 31);
+            const uint32_t term = hi32(x0) >> rb.term_sh;
+            const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
+            const bool webhead = head && !news[j];
+            const bool kept = head && (news[j] || (da[j] & SEBM25_DOC_DONE));
+            const uint64_t km = __ballot(kept), wm = __ballot(webhead);
+            // term and source of the row before (lane shifts must run with every lane active)
+            uint32_t pterm = lane_up1(term), pnews = lane_up1(news[j] ? 1u : 0u);
+            if (lane == 0) {
+                pterm = hi32(carry) >> rb.term_sh;
+                pnews = is_news(rb, carry) ? 1u : 0u;
+            }
+            if (head) {
+                const bool new_term = i == 0u || term != pterm;
+                if (new_term) row_ptr[term] = i;  // terms without rows are filled in by k_row_ptr_fill
+                if (news[j] && (new_term || !pnews)) news_ptr[term] = i;
+            }
+            carry = lane_bcast<63>(x0);
+            // a run of up to three rows (title, description, body) with tf < 2^24 each cannot overflow;
+            // longer runs (not produced by the reference's writers) are left to k_postings_fixup
+            const bool same1 = !(n1 >> 31), same2 = same1 && !(n2 >> 31), same3 = same2 && !(n3 >> 31);
+            if (__ballot(kept && same3) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
+            const uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
+            post_unit[i] = unit;
+            post_w[i] = kept ? w : POST_HOLE;
+            n_kept += (uint32_t)__popcll(km);
+            n_wh += (uint32_t)__popcll(wm);
+            n_kept_web += (uint32_t)__popcll(km & wm);
+
+            // df: web heads per term.  Rounds of a single term (the long lists) only extend a running
+            // count; a round with several terms adds one count per term segment.
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
+            if (vm == 0) {
+                // nothing of this round lies inside the range
+            } else if (__all(!valid || term == t0)) {
+                if (t0 != run_term) {
+                    if (lane == 0 && run_wh) atomicAdd(&df[run_term], run_wh);
+                    run_term = t0;
+                    run_wh = 0;
+                }
+                run_wh += (uint32_t)__popcll(wm);
+            } else {
+                if (lane == 0 && run_wh) atomicAdd(&df[run_term], run_wh);
+                run_term = NO_TERM;
+                run_wh = 0;
+                const uint32_t tprev = lane_up1(term), tnext = lane_dn1(term);
+                const uint64_t starts = __ballot(valid && (lane == 0 || term != tprev));
+                const bool next_valid = lane < 63u && ((vm >> (lane + 1u)) & 1ull);
+                if (valid && (!next_valid || tnext != term)) {
+                    const uint64_t upto = lt | (1ull << lane);
+                    const int s0 = 63 - __clzll((long long)(starts & upto));  // first lane of this lane's term
+                    const uint32_t cnt = (uint32_t)__popcll(wm & upto & ~((1ull << s0) - 1ull));
+                    if (cnt) atomicAdd(&df[term], cnt);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
-            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
-            uint64_t prev = lane_up1(r[j]);
-            if (lane == 0) prev = carry;
-            carry = lane_bcast<63>(r[j]);
-            const RowFlags fl = row_flags(r[j], prev, i == 0, i < end, fmt, doc_flags);
-            kept += (uint32_t)__popcll(__ballot(fl.kept));
-            wh += (uint32_t)__popcll(__ballot(fl.webhead));
+            ra[j] = rb1[j];
+            rb1[j] = rc[j];
+            da[j] = db[j];
         }
     }
     if (lane == 0) {
-        cnt_kept[c] = kept;
-        cnt_wh[c] = wh;
+        if (run_wh) atomicAdd(&df[run_term], run_wh);
+        if (n_kept) atomicAdd(&totals[0], (unsigned long long)n_kept);
+        if (n_wh) atomicAdd(&totals[1], (unsigned long long)n_wh);
+        if (n_kept_web) atomicAdd(&totals[5], (unsigned long long)n_kept_web);
     }
 }
 
-__global__ __launch_bounds__(RED_THREADS) void k_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows,
-                                                             uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
-                                                             const uint32_t* off_kept, const uint32_t* off_wh,
-                                                             uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
-                                                             uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                                                             uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err) {
-    const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
-    if (c >= n_chunks) return;
-    const uint32_t lane = lane_id();
-    const uint64_t lt = lanemask_lt();
-    const uint64_t begin = (uint64_t)c * chunk_rows;
-    const uint64_t end = min(R, begin + chunk_rows);
-    uint64_t carry = begin ? rows[begin - 1] : 0ull;
-    uint32_t base_k = off_kept[c], base_w = off_wh[c];
-    // rows past this wave's range are still loaded (they end runs that start inside it); the
-    // next batch is loaded before the current one is processed
-    uint64_t r[RED_ROUNDS], rn[RED_ROUNDS];
-    uint64_t after = 0, after2 = 0, after_n = 0, after2_n = 0;  // the two rows behind the batch
-#pragma unroll
-    for (int j = 0; j < RED_ROUNDS; ++j) {
-        const uint64_t i = begin + (uint64_t)j * 64u + lane;
-        r[j] = i < R ? rows[i] : 0ull;
+// Exact 64-bit weights for the runs k_postings does not handle in its fast path: more than three
+// rows of one (term, source, unit), or a tf of 2^24 or more.  One thread per row; runs only when
+// k_postings raised DEV_NEED_FIXUP.
+__global__ void k_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R || post_w[i] == POST_HOLE) return;  // only kept heads carry a weight
+    const uint64_t x0 = rows[i];
+    const bool news = fmt.src(x0) != 0u;
+    uint64_t w = 0, n = 0;
+    bool big = false;
+    for (uint64_t ii = i; ii < R; ++ii, ++n) {
+        const uint64_t x = rows[ii];
+        if (fmt.key(x) != fmt.key(x0)) break;
+        const uint32_t fc = fmt.fc(x);
+        const uint64_t tf = fmt.tf(x);
+        big |= tf >= (1ull << 24);
+        const uint64_t add = tf * (uint64_t)(news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u));
+        w = (w + add < w || w + add >= (uint64_t)POST_HOLE) ? (uint64_t)POST_HOLE : w + add;
     }
-    after = begin + RED_BATCH < R ? rows[begin + RED_BATCH] : 0ull;
-    after2 = begin + RED_BATCH + 1 < R ? rows[begin + RED_BATCH + 1] : 0ull;
-    for (uint64_t b0 = begin; b0 < end; b0 += RED_BATCH) {
-        const uint64_t nb0 = b0 + RED_BATCH;
-        if (nb0 < end) {
-#pragma unroll
-            for (int j = 0; j < RED_ROUNDS; ++j) {
-                const uint64_t i = nb0 + (uint64_t)j * 64u + lane;
-                rn[j] = i < R ? rows[i] : 0ull;
-            }
-            after_n = nb0 + RED_BATCH < R ? rows[nb0 + RED_BATCH] : 0ull;
-            after2_n = nb0 + RED_BATCH + 1 < R ? rows[nb0 + RED_BATCH + 1] : 0ull;
-        }
-#pragma unroll
-        for (int j = 0; j < RED_ROUNDS; ++j) {
-            const uint64_t i = b0 + (uint64_t)j * 64u + lane;
-            const bool valid = i < end;
-            uint64_t prev = lane_up1(r[j]);
-            if (lane == 0) prev = carry;
-            carry = lane_bcast<63>(r[j]);
-            // rows i+1 and i+2 through lane shifts; at the wave edge they are the next round's first lanes
-            const uint64_t e0 = (j + 1 < RED_ROUNDS) ? lane_bcast<0>(r[(j + 1 < RED_ROUNDS) ? j + 1 : j]) : after;
-            const uint64_t e1 = (j + 1 < RED_ROUNDS) ? lane_bcast<1>(r[(j + 1 < RED_ROUNDS) ? j + 1 : j]) : after2;
-            uint64_t r1 = lane_dn1(r[j]);
-            if (lane == 63) r1 = e0;
-            uint64_t r2 = lane_dn1(r1);
-            if (lane == 63) r2 = e1;
-            const bool first = i == 0;
-            const RowFlags fl = row_flags(r[j], prev, first, valid, fmt, doc_flags);
-            const uint64_t km = __ballot(fl.kept), wm = __ballot(fl.webhead);
-            const uint32_t p = base_k + (uint32_t)__popcll(km & lt);
-            const uint32_t wh = base_w + (uint32_t)__popcll(wm & lt);
-            const uint32_t term = fmt.term(r[j]);
-            if (fl.head) {
-                const uint32_t pterm = first ? 0u : fmt.term(prev);
-                if (first || term != pterm) {
-                    // this row opens term `term`; terms without rows before it are empty
-                    for (uint32_t x = first ? 0u : pterm + 1u; x <= term; ++x) {
-                        row_ptr[x] = p;
-                        wh_ptr[x] = wh;
-                        rs_ptr[x] = (uint32_t)i;
-                    }
-                }
-                if (fmt.src(r[j]) && (first || term != pterm || fmt.src(prev) == 0u)) news_ptr[term] = p;
-            }
-            if (fl.kept) {
-                // weight in tenths, exact: web sum_f tf_f * {32, 17, 10}[f] (W = 3.2 / 1.7 / 1.0,
-                // search_service.py:19-27), news 10 * sum tf (:84-87)
-                const uint64_t key = fmt.key(r[j]);
-                const bool news = fmt.src(r[j]) != 0u;
-                auto tenths = [&](uint64_t x) -> uint64_t {
-                    const uint32_t fc = fmt.fc(x);
-                    return fmt.tf(x) * (uint64_t)(news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u));
-                };
-                const bool same1 = (i + 1 < R) && fmt.key(r1) == key;
-                const bool same2 = same1 && (i + 2 < R) && fmt.key(r2) == key;
-                uint64_t w = tenths(r[j]) + (same1 ? tenths(r1) : 0ull) + (same2 ? tenths(r2) : 0ull);
-                if (same2) {  // more than three rows of one (term, unit): not produced by the reference's writers
-                    for (uint64_t ii = i + 3; ii < R; ++ii) {
-                        const uint64_t x = rows[ii];
-                        if (fmt.key(x) != key) break;
-                        w += tenths(x);
-                    }
-                }
-                if (w > 0xFFFFFFFFull) {
-                    atomicOr(err, DEV_ERR_RANGE);
-                    w = 0xFFFFFFFFull;
-                }
-                post_unit[p] = fmt.unit(r[j]);
-                post_w[p] = (uint32_t)w;
-            }
-            base_k += (uint32_t)__popcll(km);
-            base_w += (uint32_t)__popcll(wm);
-            if (valid && i == R - 1) {
-                const uint32_t pk = p + (fl.kept ? 1u : 0u), pw = wh + (fl.webhead ? 1u : 0u);
-                for (uint32_t x = term + 1u; x <= n_terms; ++x) {
-                    row_ptr[x] = pk;
-                    wh_ptr[x] = pw;
-                    rs_ptr[x] = (uint32_t)R;
-                }
-                totals_out[0] = pk;  // kept postings
-                totals_out[1] = pw;  // web heads (sum of df)
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < RED_ROUNDS; ++j) r[j] = rn[j];
-        after = after_n;
-        after2 = after2_n;
+    if (n <= 3 && !big) return;
+    if (w >= (uint64_t)POST_HOLE) {
+        atomicOr(err, DEV_ERR_RANGE);
+        w = POST_HOLE - 1u;
     }
+    post_w[i] = (uint32_t)w;
 }
 
-void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                         const uint8_t* doc_flags, uint32_t* cnt_kept, uint32_t* cnt_wh, hipStream_t st) {
+void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err, hipStream_t st) {
+    if (R == 0) return;
+    hipLaunchKernelGGL(k_postings_fixup, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, fmt, post_w, err);
+}
+
+void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                     const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
+                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df, uint64_t* totals, uint32_t* err,
+                     hipStream_t st) {
+    if (R == 0) return;
     const uint32_t wpb = RED_THREADS / 64;
-    hipLaunchKernelGGL(k_reduce_count, dim3((n_chunks + wpb - 1) / wpb), dim3(RED_THREADS), 0, st, rows, R, chunk_rows,
-                       n_chunks, fmt, doc_flags, cnt_kept, cnt_wh);
+    const dim3 grid((n_chunks + wpb - 1) / wpb), block(RED_THREADS);
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(totals);
+    if (doc_flags && n_docs)
+        hipLaunchKernelGGL(k_postings<true>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
+                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, tot, err);
+    else
+        hipLaunchKernelGGL(k_postings<false>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
+                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, tot, err);
 }
 
-void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                        const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
-                        uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                        uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err, hipStream_t st) {
-    const uint32_t wpb = RED_THREADS / 64;
-    hipLaunchKernelGGL(k_reduce_emit, dim3((n_chunks + wpb - 1) / wpb), dim3(RED_THREADS), 0, st, rows, R, chunk_rows,
-                       n_chunks, fmt, doc_flags, off_kept, off_wh, n_terms, post_unit, post_w, row_ptr, news_ptr, wh_ptr,
-                       rs_ptr, totals_out, err);
+// Terms without rows: row_ptr[t] = row_ptr of the next term that has rows, row_ptr[n_terms] = R.
+// First a backward minimum scan inside blocks of 1024 entries, then entries whose block holds
+// nothing behind them take the first value of the next non-empty block.
+constexpr int FILL_THREADS = 1024;
+__global__ __launch_bounds__(FILL_THREADS) void k_row_ptr_fill_blocks(uint32_t* row_ptr, uint32_t n_terms, uint32_t R,
+                                                                      uint32_t* block_first) {
+    __shared__ uint32_t sm[2][FILL_THREADS];
+    const uint32_t t = blockIdx.x * FILL_THREADS + threadIdx.x;
+    uint32_t v = t < n_terms ? row_ptr[t] : (t == n_terms ? R : 0xFFFFFFFFu);
+    int cur = 0;
+    sm[0][threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < FILL_THREADS; off <<= 1) {
+        if (threadIdx.x + off < FILL_THREADS) v = min(v, sm[cur][threadIdx.x + off]);
+        cur ^= 1;
+        sm[cur][threadIdx.x] = v;
+        __syncthreads();
+    }
+    if (t <= n_terms) row_ptr[t] = v;
+    if (threadIdx.x == 0) block_first[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void k_row_ptr_fill_rest(uint32_t* row_ptr, uint32_t n_terms, const uint32_t* block_first) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t > n_terms || row_ptr[t] != 0xFFFFFFFFu) return;
+    uint32_t b = t / FILL_THREADS + 1u;  // the last block holds row_ptr[n_terms] = R, so this ends
+    while (block_first[b] == 0xFFFFFFFFu) ++b;
+    row_ptr[t] = block_first[b];
+}
+
+size_t row_ptr_fill_tmp_words(uint32_t n_terms) { return (size_t)n_terms / FILL_THREADS + 2; }
+
+void launch_row_ptr_fill(uint32_t* row_ptr, uint32_t n_terms, uint64_t R, uint32_t* tmp, hipStream_t st) {
+    const uint32_t n = n_terms + 1u;
+    hipLaunchKernelGGL(k_row_ptr_fill_blocks, dim3((n + FILL_THREADS - 1) / FILL_THREADS), dim3(FILL_THREADS), 0, st,
+                       row_ptr, n_terms, (uint32_t)R, tmp);
+    hipLaunchKernelGGL(k_row_ptr_fill_rest, dim3((n + 255u) / 256u), dim3(256), 0, st, row_ptr, n_terms, tmp);
 }
 
 // ------------------------------------------------------------------ statistics ------------
-// df[t] = web heads of term t; term_rows[t] = input rows of term t; terms without news rows get
-// news_ptr[t] = row_ptr[t + 1] (their web segment is the whole list).
-__global__ void k_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
-                             const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows) {
+// term_rows[t] = input rows of term t; terms without news rows get news_ptr[t] = row_ptr[t + 1]
+// (their web segment is the whole list).
+__global__ void k_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_terms) return;
-    df[t] = wh_ptr[t + 1] - wh_ptr[t];
-    term_rows[t] = rs_ptr[t + 1] - rs_ptr[t];
+    term_rows[t] = row_ptr[t + 1] - row_ptr[t];
     if (news_ptr[t] == 0xFFFFFFFFu) news_ptr[t] = row_ptr[t + 1];
 }
 
-void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
-                       const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows, hipStream_t st) {
-    hipLaunchKernelGGL(k_term_stats, dim3((n_terms + 255) / 256), dim3(256), 0, st, n_terms, row_ptr, news_ptr, wh_ptr,
-                       rs_ptr, df, term_rows);
+void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_term_stats, dim3((n_terms + 255) / 256), dim3(256), 0, st, n_terms, row_ptr, news_ptr, term_rows);
 }
 
 // N, and the numerator / denominator of AVG(word_count), over documents with status 'done'

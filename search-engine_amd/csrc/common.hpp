@@ -38,8 +38,11 @@ struct RowFmt {
     __host__ __device__ uint64_t key(uint64_t r) const { return r >> key_shift(); }
 };
 
+// weight of a posting slot that holds no posting (a merged or filtered row); real weights are smaller
+constexpr uint32_t POST_HOLE = 0xFFFFFFFFu;
+
 // device error bits raised by kernels
-enum : uint32_t { DEV_ERR_RANGE = 1u, DEV_ERR_ORDER = 2u };
+enum : uint32_t { DEV_ERR_RANGE = 1u, DEV_ERR_ORDER = 2u, DEV_NEED_FIXUP = 4u };
 
 struct RawRows {
     const uint32_t* term;
@@ -95,6 +98,8 @@ constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
 constexpr int RED_THREADS = 256;
 constexpr int RED_ROUNDS = 8;                 // 64-row rounds a wave loads before it processes them
 constexpr int RED_BATCH = 64 * RED_ROUNDS;
+constexpr int POST_PAD = 2 * RED_BATCH;       // slack entries behind each posting slot array
+constexpr uint64_t MAX_ROWS = 0xFFFFF000ull;  // row indices plus a few batches of look-ahead stay 32-bit
 
 constexpr int DUMP_WORDS = 64 * SORT_ITEMS;
 
@@ -120,14 +125,16 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
 
-void launch_reduce_count(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                         const uint8_t* doc_flags, uint32_t* cnt_kept, uint32_t* cnt_wh, hipStream_t st);
-void launch_reduce_emit(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                        const uint8_t* doc_flags, const uint32_t* off_kept, const uint32_t* off_wh, uint32_t n_terms,
-                        uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* wh_ptr,
-                        uint32_t* rs_ptr, uint64_t* totals_out, uint32_t* err, hipStream_t st);
-void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, const uint32_t* wh_ptr,
-                       const uint32_t* rs_ptr, uint32_t* df, uint32_t* term_rows, hipStream_t st);
+void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
+                     const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
+                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
+                     uint64_t* totals /* [0] kept, [1] web heads, [5] kept web; zeroed */, uint32_t* err, hipStream_t st);
+// fills row_ptr entries of terms without rows (0xFFFFFFFF) and sets row_ptr[n_terms] = R
+size_t row_ptr_fill_tmp_words(uint32_t n_terms);
+void launch_row_ptr_fill(uint32_t* row_ptr, uint32_t n_terms, uint64_t R, uint32_t* tmp, hipStream_t st);
+void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err, hipStream_t st);
+void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows,
+                       hipStream_t st);
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
                       uint32_t n_docs, uint64_t* totals3 /* n_done, n_wc, sum_wc (zeroed) */, hipStream_t st);
 void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, double* idf, double* idf_used, hipStream_t st);

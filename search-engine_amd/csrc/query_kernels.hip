@@ -3,8 +3,8 @@
 //   score(unit) = SUM over query terms of idf_used[t] * w(t, unit),  matched = COUNT(DISTINCT term),
 //   ORDER BY score DESC, url ASC LIMIT k.
 //
-// One wavefront owns one work item = (query, range of unit ids).  Posting lists are sorted by
-// unit, so the wave walks all lists of the query in step through a window of WIN consecutive
+// One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a
+// range of slots sorted by unit (a few of them holes that carry no posting), so the wave walks all lists of the query in step through a window of WIN consecutive
 // unit ids whose accumulators live in LDS: 64 coalesced postings per list per load, a
 // "touched" bitmap (one 32-bit word per lane) instead of clearing accumulators, and a
 // candidate buffer that is cut back to the best k by a wave-wide bitonic sort whenever it
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
                 const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
                 const bool in = valid && (uint64_t)u < wend;
                 const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-                if (in) {
-                    const double v = __dmul_rn(idf, (double)a.post_w[i]);  // idf holds idf / 10, weights are in tenths
+                const uint32_t w = in ? a.post_w[i] : POST_HOLE;
+                if (w != POST_HOLE) {  // a hole only moves the cursor
+                    const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
                     const uint32_t idx = u - base;
                     const uint32_t bit = 1u << (idx & 31u);
                     const uint32_t old = atomicOr(&touched[idx >> 5], bit);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
             bool first = false;
             uint32_t idx = 0;
-            if (in) {
+            if (in && w != POST_HOLE) {  // a hole only moves the cursor
                 const double v = __dmul_rn(idf_t, (double)w);
                 idx = u - base;
                 const uint32_t bit = 1u << (idx & 31u);

@@ -137,3 +137,24 @@ def test_gpu_generator_matches_cpu_generator(gpu_index_factory):
     np.testing.assert_array_equal(se.zipf_cdf(5000), O.zipf_cdf(5000))
     np.testing.assert_array_equal(se.gen_queries(20260228, 5000, 50, 3, 100),
                                   O.gen_queries(20260228, 5000, O.zipf_cdf(5000), 100, 50, 3))
+
+def test_long_runs_and_huge_tf_take_the_exact_path(gpu_index_factory):
+    """More than three rows of one (term, doc) (fields the reference's writers never produce) and
+    term frequencies of 2^24 and more leave the streaming kernel's fast path: same exact weights."""
+    c = small_corpus(n_docs=300, n_terms=900, n_articles=20)
+    term, unit, tf, meta = (c[k].copy() for k in ("term_id", "unit_id", "tf", "meta"))
+    extra_t, extra_u, extra_f, extra_m = [], [], [], []
+    for doc, t in ((5, 3), (5, 4), (120, 3), (299, 899)):
+        for field, f in ((1, 7), (2, 5), (3, 2), (4, 11), (5, 1), (6, 9)):   # six rows of one (term, doc)
+            extra_t.append(t); extra_u.append(doc); extra_f.append(f); extra_m.append(se.meta(se.SRC_WEB, field))
+    for doc, t, f in ((7, 10, 1 << 24), (7, 11, (1 << 26) + 5), (200, 0, (1 << 25) + 1)):   # huge tf, single rows
+        extra_t.append(t); extra_u.append(doc); extra_f.append(f); extra_m.append(se.meta(se.SRC_WEB, 4))
+    term = np.concatenate([term, np.array(extra_t, np.uint32)])
+    unit = np.concatenate([unit, np.array(extra_u, np.uint32)])
+    tf = np.concatenate([tf, np.array(extra_f, np.uint32)])
+    meta = np.concatenate([meta, np.array(extra_m, np.uint8)])
+    c2 = dict(c, term_id=term, unit_id=unit, tf=tf, meta=meta)
+    orc = oracle_index(c2, word_count=None)
+    ix = gpu_index_factory()
+    gpu_build(ix, c2, word_count=None, unit_major=False)
+    assert_build_matches(ix, orc)
