@@ -48,6 +48,15 @@ __device__ __forceinline__ uint64_t match_digit_lds(uint32_t* tab, uint32_t d, i
     return in0 ? m0 : cand;
 }
 
+__device__ __forceinline__ uint32_t hi32(uint64_t r) { return (uint32_t)(r >> 32); }
+__device__ __forceinline__ uint32_t lo32(uint64_t r) { return (uint32_t)r; }
+// low 32 bits of (r >> sh), sh wave-uniform
+__device__ __forceinline__ uint32_t shr_lo32(uint64_t r, int sh) {
+    const uint32_t a = __builtin_amdgcn_alignbit(hi32(r), lo32(r), (uint32_t)sh & 31u);
+    const uint32_t b = hi32(r) >> ((uint32_t)sh & 31u);
+    return sh < 32 ? a : b;
+}
+
 __device__ __forceinline__ uint32_t field_code(uint32_t field) { return field == 1u ? 1u : field == 2u ? 2u : 0u; }
 
 // Cross-lane moves that stay in the vector ALU (DPP / readlane) instead of going through the LDS
@@ -89,18 +98,36 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 constexpr int HIST_THREADS = 1024;
 constexpr int HIST_UNROLL = 4;
 
-// One count per lane.  Sorted or skewed input often gives a whole wave the same digit; then
-// one lane adds the wave's population instead of 64 lanes hitting one LDS word.
-__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid) {
-    const uint64_t vm = __ballot(valid);
-    if (vm == 0) return;
-    const int first = __ffsll((unsigned long long)vm) - 1;
-    const uint32_t d0 = __shfl(d, first);
-    if (__all(!valid || d == d0)) {
-        if ((int)lane_id() == first) atomicAdd(&hist[d0], (uint32_t)__popcll(vm));
-    } else if (valid) {
-        atomicAdd(&hist[d], 1u);
+// One count per lane.  Skewed or sorted input gives many lanes of a wave the same digit, and 64
+// lanes adding to one LDS word serialise.  So the lanes that hold `hot` (the digit with the
+// largest group seen lately, carried from call to call) are counted by one add, then the group
+// of the first remaining lane by another (and becomes `hot` if it is larger); only what is left
+// after that adds lane by lane.  Where the digits turn out evenly spread the grouping is
+// skipped for the next few calls.
+struct HistState {  // wave-uniform
+    uint32_t hot = 0, plain_left = 0;
+};
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid, HistState& st) {
+    if (st.plain_left) {
+        --st.plain_left;
+        if (valid) atomicAdd(&hist[d], 1u);
+        return;
     }
+    const uint32_t lane = lane_id();
+    const bool is_hot = valid && d == st.hot;
+    const uint64_t hm = __ballot(is_hot);
+    if (hm && lane == (uint32_t)__ffsll((unsigned long long)hm) - 1u) atomicAdd(&hist[st.hot], (uint32_t)__popcll(hm));
+    const bool rest = valid && !is_hot;
+    const uint64_t rm = __ballot(rest);
+    if (rm == 0) return;
+    const int first = __ffsll((unsigned long long)rm) - 1;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+    const bool in0 = rest && d == d0;
+    const uint64_t m0 = __ballot(in0);
+    if ((int)lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(m0));
+    if (__popcll(m0) > __popcll(hm)) st.hot = d0;
+    if (__popcll(m0) + __popcll(hm) < 12) st.plain_left = 15;
+    if (rest && !in0) atomicAdd(&hist[d], 1u);
 }
 
 template <int MODE>
@@ -114,6 +141,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
     const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
     const uint64_t end = min(R, begin + chunk_rows);
     const uint64_t n = end - begin;
+    HistState hot;
     if (MODE == 0) {
         // chunk starts are multiples of the tile size, so 16-byte vector loads stay aligned
         const int sh = shift - fmt.term_shift();
@@ -130,10 +158,10 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
             for (int u = 0; u < HIST_UNROLL; ++u) {
                 const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
                 // term ids are clamped exactly as the scatter clamps them, so both agree on every digit
-                hist_add(hist, (min(x[u].x, n_terms - 1u) >> sh) & mask, ok);
-                hist_add(hist, (min(x[u].y, n_terms - 1u) >> sh) & mask, ok);
-                hist_add(hist, (min(x[u].z, n_terms - 1u) >> sh) & mask, ok);
-                hist_add(hist, (min(x[u].w, n_terms - 1u) >> sh) & mask, ok);
+                hist_add(hist, (min(x[u].x, n_terms - 1u) >> sh) & mask, ok, hot);
+                hist_add(hist, (min(x[u].y, n_terms - 1u) >> sh) & mask, ok, hot);
+                hist_add(hist, (min(x[u].z, n_terms - 1u) >> sh) & mask, ok, hot);
+                hist_add(hist, (min(x[u].w, n_terms - 1u) >> sh) & mask, ok, hot);
             }
         }
         for (uint64_t i = begin + nvec * 4 + threadIdx.x; i < end; i += HIST_THREADS)
@@ -151,8 +179,8 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
 #pragma unroll
             for (int u = 0; u < HIST_UNROLL; ++u) {
                 const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
-                hist_add(hist, (uint32_t)(x[u].x >> shift) & mask, ok);
-                hist_add(hist, (uint32_t)(x[u].y >> shift) & mask, ok);
+                hist_add(hist, shr_lo32(x[u].x, shift) & mask, ok, hot);
+                hist_add(hist, shr_lo32(x[u].y, shift) & mask, ok, hot);
             }
         }
         for (uint64_t i = begin + nvec * 2 + threadIdx.x; i < end; i += HIST_THREADS)
@@ -580,14 +608,6 @@ struct RowBits {
         term_sh = f.term_shift() - 32; unit_sh = f.unit_shift(); fc_sh = f.tf_bits;
     }
 };
-__device__ __forceinline__ uint32_t hi32(uint64_t r) { return (uint32_t)(r >> 32); }
-__device__ __forceinline__ uint32_t lo32(uint64_t r) { return (uint32_t)r; }
-// low 32 bits of (r >> sh), sh wave-uniform
-__device__ __forceinline__ uint32_t shr_lo32(uint64_t r, int sh) {
-    const uint32_t a = __builtin_amdgcn_alignbit(hi32(r), lo32(r), (uint32_t)sh & 31u);
-    const uint32_t b = hi32(r) >> ((uint32_t)sh & 31u);
-    return sh < 32 ? a : b;
-}
 __device__ __forceinline__ bool key_differs(const RowBits& b, uint64_t x, uint64_t y) {
     return (((hi32(x) ^ hi32(y)) & b.key_hi) | ((lo32(x) ^ lo32(y)) & b.key_lo)) != 0u;
 }
