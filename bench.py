@@ -128,11 +128,14 @@ def main():
     ix.enable_timing(True)
     sync()
     t0 = time.perf_counter()
+    phase_sum: dict[str, float] = {}
     for _ in range(args.steps):
         step()
+        for name, ms in ix.timings():  # HIP events around each kernel of this step, on the library's stream
+            phase_sum[name] = phase_sum.get(name, 0.0) + ms
     sync()
     elapsed = time.perf_counter() - t0
-    phases = ix.timings()  # device time of each phase of the last step
+    phases = [(n, ms / args.steps) for n, ms in phase_sum.items()]  # average launch duration per kernel
     ix.enable_timing(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -148,31 +151,52 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rows * args.steps / elapsed
 
-    # ---- roofline (per GPU): algorithmic bytes of one build / time of one build
-    alg_bytes = 13 * info.n_rows + 8 * info.n_postings + 4 * info.n_docs + 20 * info.n_terms
+    # ---- roofline of the dominant kernel (per GPU, per launch), HIP events on the library's stream
+    # algorithmic bytes per input row of each build kernel (what it must read + what it must write)
+    KERNELS = {
+        "sort_hist_0": ("k_sort_hist<0>", 4), "sort_hist_1": ("k_sort_hist<2>", 8),
+        "sort_scatter_0": ("k_sort_scatter<0>", 13 + 8),   # raw row in, packed row out
+        "sort_scatter_1": ("k_sort_scatter<2>", 8 + 8),    # packed row in, packed row out
+        "postings": ("k_postings", 8 + 8),                 # packed row in, posting slot out
+    }
     dev_ms = sum(ms for _, ms in phases)
     dom_name, dom_ms = max(phases, key=lambda p: p[1]) if phases else ("", 0.0)
-    achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+    kname, bpr = KERNELS.get(dom_name, (dom_name, 0))
+    dom_bytes = bpr * info.n_rows
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+    # HBM traffic of that kernel from rocprofv3 PMC passes (collected separately, see profiles/)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("rows") == int(info.n_rows) and kname in pmc.get("kernels", {}):
+            traffic = pmc["kernels"][kname]["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    # the whole build against the build's algorithmic bytes: 13 B/row in, 8 B/posting out, 4 B/doc, 20 B/term
+    alg_bytes = 13 * info.n_rows + 8 * info.n_postings + 4 * info.n_docs + 20 * info.n_terms
+    pipe = alg_bytes / (ms_per_step * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
-        "scope": "whole build pipeline of one GPU: algorithmic bytes (13 B/row + 8 B/posting + 4 B/doc + 20 B/term) "
-                 "over the wall time of one step",
-        "alg_bytes": alg_bytes, "device_ms_sum_of_phases": dev_ms,
-        "dominant_kernel": dom_name, "dominant_kernel_ms": dom_ms,
+        "traffic": traffic,
+        "kernel": kname, "kernel_ms": dom_ms, "alg_bytes_per_row": bpr, "alg_bytes_per_launch": dom_bytes,
+        "pipeline": {"alg_bytes": alg_bytes, "achieved": pipe, "frac": pipe / HBM_PEAK_GBS,
+                     "scope": "whole build of one GPU: 13 B/row + 8 B/posting + 4 B/doc + 20 B/term over the wall "
+                              "time of one step", "device_ms_sum_of_phases": dev_ms},
         "phases_ms": {n: round(ms, 4) for n, ms in phases},
     }
 
     out = {
         "metric": "bm25_index_build_token_rows_per_s", "value": value, "unit": "token rows/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u64 packed rows / u32 counts / f64 idf, f32 posting weights",
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"BM25 index build, {args.docs} docs per GPU, vocab {args.vocab}, Zipf s=1, "
                                f"~300 body draws/doc (BASELINE config 2 per GPU)",
                    "rows_per_gpu": int(info.n_rows), "postings_per_gpu": int(info.n_postings),
                    "sort_passes": int(info.sort_passes), "parallelism": f"doc-sharded x{world}"},
         "roofline": roofline,
+        "arithmetic": "u64 packed rows, u32 counts and posting weights (exact tenths), f64 idf and scores",
     }
 
     # ---- batched scoring on the index just built

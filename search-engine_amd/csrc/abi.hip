@@ -15,7 +15,6 @@ thread_local std::string g_thread_err;
 
 constexpr uint32_t MAX_K = 2048;
 constexpr uint32_t MAX_QUERY_TERMS = 64;
-constexpr uint32_t SORT_MAX_CHUNKS = 512;
 constexpr uint32_t RED_MAX_CHUNKS = 4096;  // wavefronts
 }  // namespace
 
@@ -38,7 +37,7 @@ struct sebm25_index {
     uint64_t N = 1;
     double avgdl = 0.0;
 
-    DevBuf sortA, sortB, chunk_hist, scan_tmp;
+    DevBuf sortA, sortB, chunk_hist, group_off, bin_start, scan_tmp;
     DevBuf row_ptr, news_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
     DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc, 5 kept web postings; u32 err at [7]; then the dump words
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
@@ -262,14 +261,18 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         const int key_bits = 64 - key_lo;
         const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
         ix->n_pass = (uint32_t)n_pass;
-        const uint32_t max_chunks = getenv("SEBM25_SORT_CHUNKS") ? (uint32_t)atoi(getenv("SEBM25_SORT_CHUNKS")) : SORT_MAX_CHUNKS;
-        uint32_t G = (uint32_t)std::min<uint64_t>((R + SORT_TILE - 1) / SORT_TILE, max_chunks);
-        uint64_t chunk_rows = (R + G - 1) / G;
-        chunk_rows = (chunk_rows + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
-        G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
-        const size_t hist_words = (size_t)SORT_MAX_BINS * G;
-        HIP_TRY(ix, ix->chunk_hist.ensure(hist_words * 4));
-        HIP_TRY(ix, ix->scan_tmp.ensure(scan_tmp_words(hist_words) * 4));
+        // Rows per chunk, by pass: the more bins a pass has, the shorter a tile's run per bin and the more
+        // it matters that neighbouring runs are written at about the same time, so the widest digits
+        // take one tile per chunk.  SEBM25_SORT_CHUNK_TILES (1..8) overrides, for experiments.
+        const int forced_tiles = getenv("SEBM25_SORT_CHUNK_TILES") ? std::min(8, std::max(1, atoi(getenv("SEBM25_SORT_CHUNK_TILES")))) : 0;
+        auto chunk_rows_of = [&](int bits) -> uint64_t {
+            return (uint64_t)(forced_tiles ? forced_tiles : (bits >= SORT_MAX_BITS ? 1 : SORT_CHUNK_TILES)) * SORT_TILE;
+        };
+        const uint32_t G = (uint32_t)((R + SORT_TILE - 1) / SORT_TILE);  // most chunks any pass can have
+        const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
+        HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 4));
+        HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
+        HIP_TRY(ix, ix->bin_start.ensure((size_t)SORT_MAX_BINS * 4));
 
         BuildCtx ctx{};
         ctx.fmt = fmt;
@@ -292,15 +295,20 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
             const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
             const int mode = p == 0 ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
             uint64_t* dst = bufs[p & 1];
-            const size_t words = ((size_t)1 << bits) * G;
+            const uint64_t chunk_rows = chunk_rows_of(bits);
+            const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
+            const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
+            uint32_t* prefix = ix->chunk_hist.as<uint32_t>();
+            uint32_t* group_off = ix->group_off.as<uint32_t>();
+            uint32_t* bin_start = ix->bin_start.as<uint32_t>();
             phase_begin(ix, hist_names[p]);
-            launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, ix->chunk_hist.as<uint32_t>(), ix->stream);
+            launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, ix->stream);
             phase_end(ix);
             phase_begin(ix, scan_names[p]);
-            launch_exclusive_scan_u32(ix->chunk_hist.as<uint32_t>(), words, ix->scan_tmp.as<uint32_t>(), ix->stream);
+            launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->stream);
             phase_end(ix);
             phase_begin(ix, scat_names[p]);
-            launch_sort_scatter(mode, raw, src_packed, dst, R, chunk_rows, G, shift, bits, ctx, ix->chunk_hist.as<uint32_t>(), ix->stream);
+            launch_sort_scatter(mode, raw, src_packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start, ix->stream);
             phase_end(ix);
             src_packed = dst;
             shift += bits;
@@ -394,7 +402,7 @@ void sebm25_destroy(sebm25_index* ix) {
     {
         DeviceGuard g(ix->device);
         (void)hipStreamSynchronize(ix->stream);
-        DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->scan_tmp, &ix->row_ptr, &ix->news_ptr,
+        DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->group_off, &ix->bin_start, &ix->scan_tmp, &ix->row_ptr, &ix->news_ptr,
                          &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
                          &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
                          &ix->st_flags, &ix->st_misc, &ix->url_rank_web, &ix->url_rank_news, &ix->q_items, &ix->q_terms,

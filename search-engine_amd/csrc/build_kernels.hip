@@ -90,8 +90,14 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ------------------------------------------------------------------ histogram (upsweep) ---
-// Workgroup g counts the digits of its chunk of rows; counts are stored bin-major
-// (chunk_hist[bin * G + g]) so that one flat exclusive scan yields every chunk's write base.
+// Rows are cut into chunks of SORT_CHUNK_TILES tiles, chunks into groups of SORT_GROUP.  A
+// workgroup counts the digits of the chunks of one group, one chunk after the other, and writes
+// for every chunk the counts of the group's earlier chunks (prefix[chunk][bin], coalesced) and at
+// the end the group's totals (group_tot[group][bin]).  A chunk's write base for a bin is then
+//   bin_base[bin] + group_off[group][bin] + prefix[chunk][bin]
+// with group_off the exclusive scan of group_tot down the groups and bin_base the exclusive scan
+// of the bin totals.  Chunks are small, so that the workgroups of one XCD, which take consecutive
+// chunks, append to each bin next to one another and their runs merge into full lines in L2.
 // MODE 0: raw rows, only term_id is read (the digit lies inside the term bits)
 // MODE 1: raw rows, digit taken from the key packed from term / source / unit
 // MODE 2: packed rows
@@ -107,16 +113,20 @@ constexpr int HIST_UNROLL = 4;
 struct HistState {  // wave-uniform
     uint32_t hot = 0, plain_left = 0;
 };
+// hist holds two 16-bit counters per word (a chunk has fewer than 2^16 rows)
+__device__ __forceinline__ void hist_bump(uint32_t* hist, uint32_t d, uint32_t n) {
+    atomicAdd(&hist[d >> 1], n << ((d & 1u) * 16u));
+}
 __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid, HistState& st) {
     if (st.plain_left) {
         --st.plain_left;
-        if (valid) atomicAdd(&hist[d], 1u);
+        if (valid) hist_bump(hist, d, 1u);
         return;
     }
     const uint32_t lane = lane_id();
     const bool is_hot = valid && d == st.hot;
     const uint64_t hm = __ballot(is_hot);
-    if (hm && lane == (uint32_t)__ffsll((unsigned long long)hm) - 1u) atomicAdd(&hist[st.hot], (uint32_t)__popcll(hm));
+    if (hm && lane == (uint32_t)__ffsll((unsigned long long)hm) - 1u) hist_bump(hist, st.hot, (uint32_t)__popcll(hm));
     const bool rest = valid && !is_hot;
     const uint64_t rm = __ballot(rest);
     if (rm == 0) return;
@@ -124,77 +134,131 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid,
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
     const bool in0 = rest && d == d0;
     const uint64_t m0 = __ballot(in0);
-    if ((int)lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(m0));
+    if ((int)lane == first) hist_bump(hist, d0, (uint32_t)__popcll(m0));
     if (__popcll(m0) > __popcll(hm)) st.hot = d0;
     if (__popcll(m0) + __popcll(hm) < 12) st.plain_left = 15;
-    if (rest && !in0) atomicAdd(&hist[d], 1u);
+    if (rest && !in0) hist_bump(hist, d, 1u);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const uint64_t* packed, uint64_t R,
                                                             uint64_t chunk_rows, uint32_t G, int shift, int bits,
-                                                            RowFmt fmt, uint32_t n_terms, uint32_t* chunk_hist) {
-    __shared__ uint32_t hist[SORT_MAX_BINS];
+                                                            RowFmt fmt, uint32_t n_terms, uint32_t* prefix,
+                                                            uint32_t* group_tot) {
+    // one wavefront per chunk of the group, each with its own histogram: no barriers while counting
+    __shared__ uint32_t hist[SORT_GROUP][SORT_MAX_BINS / 2];
+    static_assert(HIST_THREADS == SORT_GROUP * 64, "one wavefront per chunk of a group");
     const uint32_t nb = 1u << bits, mask = nb - 1u;
-    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) hist[d] = 0;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    for (uint32_t x = threadIdx.x; x < SORT_GROUP * SORT_MAX_BINS / 2; x += HIST_THREADS) (&hist[0][0])[x] = 0;
     __syncthreads();
-    const uint64_t begin = (uint64_t)blockIdx.x * chunk_rows;
-    const uint64_t end = min(R, begin + chunk_rows);
-    const uint64_t n = end - begin;
-    HistState hot;
-    if (MODE == 0) {
-        // chunk starts are multiples of the tile size, so 16-byte vector loads stay aligned
-        const int sh = shift - fmt.term_shift();
-        const uint4* p = reinterpret_cast<const uint4*>(raw.term + begin);
-        const uint64_t nvec = n / 4;
-        for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)HIST_THREADS * HIST_UNROLL) {
-            uint4 x[HIST_UNROLL];
+    const uint32_t g_begin = blockIdx.x * SORT_GROUP;
+    const uint32_t g = g_begin + wave;
+    if (g < G) {
+        uint32_t* h = hist[wave];
+        HistState hot;
+        const uint64_t begin = (uint64_t)g * chunk_rows;
+        const uint64_t end = min(R, begin + chunk_rows);
+        const uint64_t n = end - begin;
+        uint64_t done = 0;  // rows counted by the vector loop
+        if (MODE == 0) {
+            // chunk starts are multiples of the tile size, so 16-byte vector loads stay aligned
+            const int sh = shift - fmt.term_shift();
+            const uint4* p = reinterpret_cast<const uint4*>(raw.term + begin);
+            const uint64_t nvec = n / 4;
+            for (uint64_t v0 = 0; v0 < nvec; v0 += 64u * HIST_UNROLL) {
+                uint4 x[HIST_UNROLL];
 #pragma unroll
-            for (int u = 0; u < HIST_UNROLL; ++u) {
-                const uint64_t v = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x;
-                x[u] = v < nvec ? p[v] : make_uint4(0, 0, 0, 0);
-            }
+                for (int u = 0; u < HIST_UNROLL; ++u) {
+                    const uint64_t v = v0 + (uint64_t)u * 64u + lane;
+                    x[u] = v < nvec ? p[v] : make_uint4(0, 0, 0, 0);
+                }
 #pragma unroll
-            for (int u = 0; u < HIST_UNROLL; ++u) {
-                const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
-                // term ids are clamped exactly as the scatter clamps them, so both agree on every digit
-                hist_add(hist, (min(x[u].x, n_terms - 1u) >> sh) & mask, ok, hot);
-                hist_add(hist, (min(x[u].y, n_terms - 1u) >> sh) & mask, ok, hot);
-                hist_add(hist, (min(x[u].z, n_terms - 1u) >> sh) & mask, ok, hot);
-                hist_add(hist, (min(x[u].w, n_terms - 1u) >> sh) & mask, ok, hot);
+                for (int u = 0; u < HIST_UNROLL; ++u) {
+                    const bool ok = v0 + (uint64_t)u * 64u + lane < nvec;
+                    // term ids are clamped exactly as the scatter clamps them, so both agree on every digit
+                    hist_add(h, (min(x[u].x, n_terms - 1u) >> sh) & mask, ok, hot);
+                    hist_add(h, (min(x[u].y, n_terms - 1u) >> sh) & mask, ok, hot);
+                    hist_add(h, (min(x[u].z, n_terms - 1u) >> sh) & mask, ok, hot);
+                    hist_add(h, (min(x[u].w, n_terms - 1u) >> sh) & mask, ok, hot);
+                }
             }
+            done = nvec * 4;
+        } else if (MODE == 2) {
+            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(packed + begin);
+            const uint64_t nvec = n / 2;
+            for (uint64_t v0 = 0; v0 < nvec; v0 += 64u * HIST_UNROLL) {
+                ulonglong2 x[HIST_UNROLL];
+#pragma unroll
+                for (int u = 0; u < HIST_UNROLL; ++u) {
+                    const uint64_t v = v0 + (uint64_t)u * 64u + lane;
+                    x[u] = v < nvec ? p[v] : make_ulonglong2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < HIST_UNROLL; ++u) {
+                    const bool ok = v0 + (uint64_t)u * 64u + lane < nvec;
+                    hist_add(h, shr_lo32(x[u].x, shift) & mask, ok, hot);
+                    hist_add(h, shr_lo32(x[u].y, shift) & mask, ok, hot);
+                }
+            }
+            done = nvec * 2;
         }
-        for (uint64_t i = begin + nvec * 4 + threadIdx.x; i < end; i += HIST_THREADS)
-            atomicAdd(&hist[(min(raw.term[i], n_terms - 1u) >> sh) & mask], 1u);
-    } else if (MODE == 2) {
-        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(packed + begin);
-        const uint64_t nvec = n / 2;
-        for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)HIST_THREADS * HIST_UNROLL) {
-            ulonglong2 x[HIST_UNROLL];
-#pragma unroll
-            for (int u = 0; u < HIST_UNROLL; ++u) {
-                const uint64_t v = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x;
-                x[u] = v < nvec ? p[v] : make_ulonglong2(0, 0);
+        // what the vector loop left (MODE 1: everything), one row per lane
+        for (uint64_t i0 = begin + done; i0 < end; i0 += 64u) {
+            const uint64_t i = i0 + lane;
+            const bool ok = i < end;
+            uint32_t d = 0;
+            if (ok) {
+                if (MODE == 0) {
+                    d = (min(raw.term[i], n_terms - 1u) >> (shift - fmt.term_shift())) & mask;
+                } else if (MODE == 2) {
+                    d = shr_lo32(packed[i], shift) & mask;
+                } else {
+                    const uint32_t m = raw.meta[i];
+                    const uint64_t key = fmt.pack(min(raw.term[i], n_terms - 1u), ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u,
+                                                  raw.unit[i] & (uint32_t)((1ull << fmt.unit_bits) - 1ull), 0u, 0ull);
+                    d = (uint32_t)(key >> shift) & mask;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < HIST_UNROLL; ++u) {
-                const bool ok = v0 + (uint64_t)u * HIST_THREADS + threadIdx.x < nvec;
-                hist_add(hist, shr_lo32(x[u].x, shift) & mask, ok, hot);
-                hist_add(hist, shr_lo32(x[u].y, shift) & mask, ok, hot);
-            }
-        }
-        for (uint64_t i = begin + nvec * 2 + threadIdx.x; i < end; i += HIST_THREADS)
-            atomicAdd(&hist[(uint32_t)(packed[i] >> shift) & mask], 1u);
-    } else {
-        for (uint64_t i = begin + threadIdx.x; i < end; i += HIST_THREADS) {
-            const uint32_t m = raw.meta[i];
-            const uint64_t key = fmt.pack(min(raw.term[i], n_terms - 1u), ((m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u,
-                                          raw.unit[i] & (uint32_t)((1ull << fmt.unit_bits) - 1ull), 0u, 0ull);
-            atomicAdd(&hist[(uint32_t)(key >> shift) & mask], 1u);
+            hist_add(h, d, ok, hot);
         }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) chunk_hist[(size_t)d * G + blockIdx.x] = hist[d];
+    // counts of the group's earlier chunks, per chunk and bin; group totals
+    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) {
+        uint32_t run = 0;
+#pragma unroll 4
+        for (uint32_t w = 0; w < SORT_GROUP; ++w) {
+            if (g_begin + w < G) {
+                prefix[(size_t)(g_begin + w) * nb + d] = run;
+                run += (hist[w][d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+            }
+        }
+        group_tot[(size_t)blockIdx.x * nb + d] = run;
+    }
+}
+
+// group_tot[group][bin] -> exclusive scan down the groups, in place; bin_tot[bin] = column total.
+// One wavefront per bin.
+__global__ __launch_bounds__(256) void k_sort_group_scan(uint32_t* group_tot, uint32_t n_groups, uint32_t nb,
+                                                         uint32_t* bin_tot) {
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const uint32_t lane = lane_id();
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const uint32_t v = g < n_groups ? group_tot[(size_t)g * nb + b] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t x = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += x;
+        }
+        if (g < n_groups) group_tot[(size_t)g * nb + b] = carry + inc - v;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) bin_tot[b] = carry;
 }
 
 // ------------------------------------------------------------------ scatter (downsweep) ---
@@ -227,7 +291,8 @@ constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-l
 template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                uint64_t R, uint64_t chunk_rows, uint32_t G, int shift,
-                                                               int bits, BuildCtx ctx, const uint32_t* chunk_off) {
+                                                               int bits, BuildCtx ctx, const uint32_t* prefix,
+                                                               const uint32_t* group_off, const uint32_t* bin_start) {
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
     __shared__ uint32_t mtab[SORT_WAVES][2 << MATCH_TAB_BITS];  // per wave: lane masks per folded digit
     __shared__ uint64_t rows_s[SORT_TILE];                      // the tile, locally ordered by digit
@@ -249,7 +314,8 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
     const uint64_t end = min(R, begin + chunk_rows);
     if (begin >= end) return;
     uint32_t* wh32 = reinterpret_cast<uint32_t*>(&whist[0][0]);  // two 16-bit counters per word
-    for (uint32_t d = t; d < nb; d += SORT_THREADS) bin_base[d] = chunk_off[(size_t)d * G + chunk];
+    for (uint32_t d = t; d < nb; d += SORT_THREADS)
+        bin_base[d] = bin_start[d] + group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
     for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
     for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS); x += SORT_THREADS) (&mtab[0][0])[x] = 0;
     if (MODE != 2) dl_s[t] = 0;
@@ -460,26 +526,35 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
 }
 
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
-                      int shift, int bits, const BuildCtx& ctx, uint32_t* chunk_hist, hipStream_t st) {
-    dim3 grid(G), block(HIST_THREADS);
+                      int shift, int bits, const BuildCtx& ctx, uint32_t* prefix, uint32_t* group_tot, hipStream_t st) {
+    dim3 grid((G + SORT_GROUP - 1) / SORT_GROUP), block(HIST_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, prefix, group_tot);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_hist<1>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<1>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, prefix, group_tot);
     else
-        hipLaunchKernelGGL(k_sort_hist<2>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, chunk_hist);
+        hipLaunchKernelGGL(k_sort_hist<2>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, prefix, group_tot);
+}
+
+__global__ void k_scan_single(uint32_t* sums, size_t n);
+
+// group_tot -> group offsets (in place); bin_tot -> first slot of every bin (in place)
+void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot, hipStream_t st) {
+    const uint32_t nb = 1u << bits;
+    hipLaunchKernelGGL(k_sort_group_scan, dim3((nb + 3u) / 4u), dim3(256), 0, st, group_tot, n_groups, nb, bin_tot);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bin_tot, (size_t)nb);
 }
 
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
                          uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                         const uint32_t* chunk_off, hipStream_t st) {
+                         const uint32_t* prefix, const uint32_t* group_off, const uint32_t* bin_start, hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_scatter<0>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
+        hipLaunchKernelGGL(k_sort_scatter<0>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_scatter<1>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
+        hipLaunchKernelGGL(k_sort_scatter<1>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
     else
-        hipLaunchKernelGGL(k_sort_scatter<2>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, chunk_off);
+        hipLaunchKernelGGL(k_sort_scatter<2>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------

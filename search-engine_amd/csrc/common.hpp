@@ -94,6 +94,8 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SORT_MAX_BITS = 10;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
+constexpr int SORT_CHUNK_TILES = 2;   // tiles per chunk (the unit of work of one scatter workgroup)
+constexpr int SORT_GROUP = 16;        // chunks per histogram workgroup
 
 constexpr int RED_THREADS = 256;
 constexpr int RED_ROUNDS = 8;                 // 64-row rounds a wave loads before it processes them
@@ -117,10 +119,12 @@ struct BuildCtx {
 // sort_mode: 0 raw rows, digit taken from term_id alone; 1 raw rows, digit from the packed
 // key; 2 packed rows.
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
-                      int shift, int bits, const BuildCtx& ctx, uint32_t* chunk_hist, hipStream_t st);
+                      int shift, int bits, const BuildCtx& ctx, uint32_t* prefix /* [G][bins] */,
+                      uint32_t* group_tot /* [groups][bins] */, hipStream_t st);
+void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot /* [bins] */, hipStream_t st);
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
                          uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                         const uint32_t* chunk_off, hipStream_t st);
+                         const uint32_t* prefix, const uint32_t* group_off, const uint32_t* bin_start, hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
