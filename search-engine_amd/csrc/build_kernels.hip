@@ -14,39 +14,11 @@ namespace sebm25 {
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Lanes of the wave that hold the same `bits`-bit digit as this lane (only among `valid`), found
-// through LDS instead of one ballot per digit bit.  The group of the first
-// valid lane (the hot digit of a skewed or sorted round) is taken by one compare; every other
-// lane ORs its lane bit into a per-wave table slot chosen by the low MATCH_TAB_BITS digit bits,
-// reads the slot back (all lanes that share those bits), and the remaining high bits are settled
-// by ballots.  Slots are cleared again by their lowest lane.  tab: 2 words (lanes 0-31, 32-63)
-// per slot, all zero between calls.  A wave's LDS operations complete in issue order.
+// Digit matching in the scatter kernel: which lanes of a wave hold the same digit.  Every lane
+// ORs its lane bit into a per-wave LDS table slot chosen by the low MATCH_TAB_BITS digit bits and
+// reads the slot back (all lanes that share those bits); remaining high bits are settled by
+// ballots.  Table: 2 words (lanes 0-31, 32-63) per slot, all zero between uses.
 constexpr int MATCH_TAB_BITS = 8;
-__device__ __forceinline__ uint64_t match_digit_lds(uint32_t* tab, uint32_t d, int bits, bool valid) {
-    const uint32_t lane = lane_id();
-    const uint64_t vm = __ballot(valid);
-    if (vm == 0) return 0;
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __ffsll((unsigned long long)vm) - 1);
-    const bool in0 = valid && d == d0;
-    const uint64_t m0 = __ballot(in0);
-    const bool rest = valid && !in0;
-    uint64_t cand = 0;
-    if (__ballot(rest)) {
-        const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
-        if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
-        __builtin_amdgcn_wave_barrier();
-        if (rest) cand = *reinterpret_cast<const uint64_t*>(&tab[slot]);
-        const uint64_t raw = cand;
-        for (int b = MATCH_TAB_BITS; b < bits; ++b) {
-            const bool one = (d >> b) & 1u;
-            const uint64_t bal = __ballot(one);
-            cand &= one ? bal : ~bal;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (rest && (raw & lanemask_lt()) == 0) *reinterpret_cast<uint64_t*>(&tab[slot]) = 0ull;
-    }
-    return in0 ? m0 : cand;
-}
 
 __device__ __forceinline__ uint32_t hi32(uint64_t r) { return (uint32_t)(r >> 32); }
 __device__ __forceinline__ uint32_t lo32(uint64_t r) { return (uint32_t)r; }
@@ -418,22 +390,59 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
         }
         STAMP(0);  // rows available and packed
 
-        // ---- rank: position of each row among the rows of its digit held by this wave
+        // ---- rank: position of each row among the rows of its digit held by this wave.
+        // The lanes that share a digit are found through the wave's LDS table (see MATCH_TAB_BITS),
+        // for all rounds at once: a wave's LDS operations execute in issue order, so round j + 1
+        // may mark its slots before round j's masks have come back, as long as every lane that marked
+        // a slot also clears it again.  Only then are the masks waited for, once.
         uint32_t rk[SORT_ITEMS];
+        {
+            uint32_t* tab = mtab[wave];
+            uint32_t dg[SORT_ITEMS];
+            uint64_t cand[SORT_ITEMS], m0[SORT_ITEMS];
+            uint32_t in0_bits = 0, valid_bits = 0;
 #pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) {
-            const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-            const bool valid = i < end;
-            const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
-            const uint64_t peers = match_digit_lds(mtab[wave], d, bits, valid);
-            // every lane of a digit group reads the group's running count (one address: a broadcast),
-            // then its first lane adds the group's size
-            uint32_t old = 0;
-            if (valid) old = whist[wave][d];
-            __builtin_amdgcn_wave_barrier();
-            if (valid && (peers & lanemask_lt()) == 0) whist[wave][d] = (unsigned short)(old + (uint32_t)__popcll(peers));
-            rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
-            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < SORT_ITEMS; ++j) {
+                const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
+                const bool valid = i < end;
+                const uint32_t d = shr_lo32(row[j], shift) & mask;
+                dg[j] = d;
+                const uint64_t vm = __ballot(valid);
+                // the group of the first valid lane (the hot digit of skewed or sorted rows) by one compare
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, vm ? __ffsll((unsigned long long)vm) - 1 : 0);
+                const bool in0 = valid && d == d0;
+                m0[j] = __ballot(in0);
+                const bool rest = valid && !in0;
+                valid_bits |= (valid ? 1u : 0u) << j;
+                in0_bits |= (in0 ? 1u : 0u) << j;
+                const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
+                cand[j] = 0;
+                if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
+                __builtin_amdgcn_wave_barrier();
+                if (rest) cand[j] = *reinterpret_cast<const uint64_t*>(&tab[slot]);
+                __builtin_amdgcn_wave_barrier();
+                if (rest) *reinterpret_cast<uint64_t*>(&tab[slot]) = 0ull;
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) {
+                const bool valid = (valid_bits >> j) & 1u;
+                uint64_t peers = cand[j];  // lanes that share the low digit bits: settle the high bits
+                for (int b = MATCH_TAB_BITS; b < bits; ++b) {
+                    const bool one = (dg[j] >> b) & 1u;
+                    const uint64_t bal = __ballot(one);
+                    peers &= one ? bal : ~bal;
+                }
+                if ((in0_bits >> j) & 1u) peers = m0[j];
+                // every lane of a digit group reads the group's running count (one address: a broadcast),
+                // then its first lane adds the group's size
+                uint32_t old = 0;
+                if (valid) old = whist[wave][dg[j]];
+                __builtin_amdgcn_wave_barrier();
+                if (valid && (peers & lanemask_lt()) == 0) whist[wave][dg[j]] = (unsigned short)(old + (uint32_t)__popcll(peers));
+                rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         STAMP(1);  // ranked
         __syncthreads();
