@@ -38,24 +38,26 @@ def parse():
     ap.add_argument("--terms-per-query", type=int, default=3)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--query-steps", type=int, default=5)
-    ap.add_argument("--cpu-docs", type=int, default=100_000, help="docs in the CPU-baseline sample")
+    ap.add_argument("--cpu-docs", type=int, default=1_000_000, help="docs in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (a single-threaded C restatement of the reference's SQL) timed on a
-    bounded sample of the same synthetic workload.  Checker code, never the product path."""
+def cpu_baseline(args, rows):
+    """The CPU oracle (a single-threaded C restatement of the reference's SQL) timed on the first
+    `cpu_docs` documents of the same synthetic corpus (the rows come from the GPU generator, which
+    the tests hold bit-identical to the oracle's own).  Checker code, never the product path."""
+    import numpy as np
+
     from oracle import oracle as O
 
-    spec = O.make_spec(n_terms=args.vocab, n_docs=args.cpu_docs)
-    c = O.gen_corpus(spec)
-    rows = len(c["term_id"])
+    term, unit, tf, meta, wc, n_docs = rows
+    n = len(term)
     t0 = time.perf_counter()
-    orc = O.OracleIndex(c["term_id"], c["unit_id"], c["tf"], c["meta"], c["n_terms"], c["n_docs"], 0, c["word_count"])
+    orc = O.OracleIndex(term, unit, tf, meta, args.vocab, n_docs, 0, wc)
     t_build = time.perf_counter() - t0
-    nq = 200
+    nq = 1000
     qs = O.gen_queries(20260228, args.vocab, O.zipf_cdf(args.vocab), 100, nq, args.terms_per_query)
     t0 = time.perf_counter()
     for q in qs:
@@ -63,11 +65,11 @@ def cpu_baseline(args):
     t_q = time.perf_counter() - t0
     orc.close()
     return {
-        "value": rows / t_build, "unit": "token rows/s", "cores": 1, "kind": "port",
-        "sample": f"{args.cpu_docs} docs / {rows} rows of the same synthetic corpus, single-threaded C oracle "
+        "value": n / t_build, "unit": "token rows/s", "cores": 1, "kind": "port",
+        "sample": f"{n_docs} docs / {n} rows of the same synthetic corpus, single-threaded C oracle "
                   f"(sort + collapse + df + idf), {t_build:.2f} s",
         "queries_per_s": nq / t_q,
-        "query_sample": f"{nq} queries x {args.terms_per_query} terms, top-{args.k}, over the {args.cpu_docs}-doc sample, {t_q:.2f} s",
+        "query_sample": f"{nq} queries x {args.terms_per_query} terms, top-{args.k}, over the {n_docs}-doc sample, {t_q:.2f} s",
     }
 
 
@@ -238,7 +240,14 @@ def main():
         }
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args)
+        # rows of the first cpu_docs documents: a prefix of the unit-major corpus
+        cpu_docs = min(args.cpu_docs, args.docs)
+        n_cpu = ix.gen_corpus_rows(se.make_spec(n_terms=args.vocab, n_docs=cpu_docs)) if args.articles == 0 else 0
+        if n_cpu:
+            host = [x[:n_cpu].cpu().numpy().view(dt) for x, dt in
+                    ((term, np.uint32), (unit, np.uint32), (tf, np.uint32), (meta, np.uint8))]
+            host.append(wc[:cpu_docs].cpu().numpy().view(np.uint32))
+            out["cpu_baseline"] = cpu_baseline(args, host + [cpu_docs])
 
     if rank == 0:
         print(json.dumps(out))

@@ -239,10 +239,12 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
-// Fast path for queries with at most FAST_T lists.  Each list keeps its next 64 postings in
-// registers, loaded one window ahead, so a window normally touches no global memory on its
-// critical path; the doc ids first touched in a window are appended to a dense list, so the
-// harvest offers 64 candidates per step instead of scanning a sparse bitmap.
+// Fast path for queries with at most FAST_T lists.  Each list is read in chunks of 64 slots
+// aligned to 64 (one coalesced load of units, one of weights); three chunks per list sit in
+// registers and the fourth is requested the moment the first is used up, two chunks before its
+// data is needed, so a window normally touches no global memory on its critical path.  The doc
+// ids first touched in a window are appended to a dense list, so the harvest offers 64
+// candidates per step instead of scanning a sparse bitmap.
 constexpr int FAST_T = 4;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -276,21 +278,32 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
         my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
     }
-    // per list: cursor, end, and the next 2 x 64 postings in registers
-    uint32_t cur[FAST_T], end[FAST_T], bu0[FAST_T], bu1[FAST_T];
-    uint32_t bw0[FAST_T], bw1[FAST_T];
+    // per list: slot index of the current chunk's lane 0, first unconsumed lane of that chunk, end
+    // of the list, and three chunks of units / weights (slots outside [cursor, end) read as INF)
+    uint32_t pos[FAST_T], off[FAST_T], end[FAST_T];
+    uint32_t u0[FAST_T], u1[FAST_T], u2[FAST_T], w0[FAST_T], w1[FAST_T], w2[FAST_T];
     double idf[FAST_T];
+    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& u, uint32_t& w) {
+        const uint32_t i = p + lane;
+        const bool ok = i >= lo && i < end[t];
+        u = ok ? a.post_unit[i] : INF;
+        w = ok ? a.post_w[i] : POST_HOLE;
+    };
 #pragma unroll
     for (int t = 0; t < FAST_T; ++t) {
-        cur[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
         end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
         idf[t] = readlane_f64(my_idf, t);
-        const uint32_t i0 = cur[t] + lane, i1 = i0 + 64u;
-        const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
-        bu0[t] = ok0 ? a.post_unit[i0] : INF;
-        bw0[t] = ok0 ? a.post_w[i0] : 0u;
-        bu1[t] = ok1 ? a.post_unit[i1] : INF;
-        bw1[t] = ok1 ? a.post_w[i1] : 0u;
+        pos[t] = cur & ~63u;
+        off[t] = cur & 63u;
+        if (cur >= end[t]) {  // empty list (or t >= T): nothing to read
+            pos[t] = 0;
+            off[t] = 0;
+            end[t] = 0;
+        }
+        load_chunk(t, pos[t], cur, u0[t], w0[t]);
+        load_chunk(t, pos[t] + 64u, cur, u1[t], w1[t]);
+        load_chunk(t, pos[t] + 128u, cur, u2[t], w2[t]);
     }
     if (lane < WINSZ / 32) touched[lane] = 0;
     TopK<CAP> tk;
@@ -299,69 +312,52 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
     __builtin_amdgcn_wave_barrier();
 
     while (true) {
+        // window start: the smallest unit any list still has to deliver
         uint32_t nxt = INF;
 #pragma unroll
         for (int t = 0; t < FAST_T; ++t)
-            if (cur[t] < end[t]) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readfirstlane((int)bu0[t]));
+            if ((uint32_t)t < T) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], (int)off[t]));
         if (nxt == INF) break;
         const uint32_t base = nxt & ~31u;
         const uint64_t wend = (uint64_t)base + WINSZ;
 
-        // adds the in-window postings of one 64-posting chunk; returns how many there were
-        auto consume = [&](uint32_t u, uint32_t w, double idf_t) -> uint32_t {
-            const bool in = u != INF && (uint64_t)u < wend;
-            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-            bool first = false;
-            uint32_t idx = 0;
-            if (in && w != POST_HOLE) {  // a hole only moves the cursor
-                const double v = __dmul_rn(idf_t, (double)w);
-                idx = u - base;
-                const uint32_t bit = 1u << (idx & 31u);
-                const uint32_t old = atomicOr(&touched[idx >> 5], bit);
-                first = !(old & bit);
-                if (first) {
-                    acc[idx] = v;
-                    cnt[idx] = 1;
-                } else {
-                    acc[idx] = __dadd_rn(acc[idx], v);
-                    cnt[idx] = (unsigned char)(cnt[idx] + 1);
-                }
-            }
-            const uint64_t om = __ballot(first);
-            if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
-            n_o += (uint32_t)__popcll(om);
-            return n_in;
-        };
-
 #pragma unroll
         for (int t = 0; t < FAST_T; ++t) {
-            if (cur[t] < end[t]) {
-                uint32_t c = cur[t];
-                uint32_t n_in = consume(bu0[t], bw0[t], idf[t]);
-                c += n_in;
-                if (n_in == 64) {
-                    n_in = consume(bu1[t], bw1[t], idf[t]);
-                    c += n_in;
-                    while (n_in == 64) {  // a dense list: the window holds more than 128 of its postings
-                        const uint32_t i = c + lane;
-                        const bool ok = i < end[t];
-                        n_in = consume(ok ? a.post_unit[i] : INF, ok ? a.post_w[i] : 0u, idf[t]);
-                        c += n_in;
+            if ((uint32_t)t >= T) break;
+            while (true) {
+                // the unconsumed slots of the current chunk that fall into the window
+                const bool in = lane >= off[t] && u0[t] != INF && (uint64_t)u0[t] < wend;
+                const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                bool first = false;
+                uint32_t idx = 0;
+                if (in && w0[t] != POST_HOLE) {  // a hole only moves the cursor
+                    const double v = __dmul_rn(idf[t], (double)w0[t]);
+                    idx = u0[t] - base;
+                    const uint32_t bit = 1u << (idx & 31u);
+                    const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                    first = !(old & bit);
+                    if (first) {
+                        acc[idx] = v;
+                        cnt[idx] = 1;
+                    } else {
+                        acc[idx] = __dadd_rn(acc[idx], v);
+                        cnt[idx] = (unsigned char)(cnt[idx] + 1);
                     }
                 }
-                if (c != cur[t]) {
-                    // refill two chunks ahead: the second one brings the lines of later windows into
-                    // the cache long before they are needed
-                    cur[t] = c;
-                    const uint32_t i0 = c + lane, i1 = i0 + 64u;
-                    const bool ok0 = i0 < end[t], ok1 = i1 < end[t];
-                    bu0[t] = ok0 ? a.post_unit[i0] : INF;
-                    bw0[t] = ok0 ? a.post_w[i0] : 0u;
-                    bu1[t] = ok1 ? a.post_unit[i1] : INF;
-                    bw1[t] = ok1 ? a.post_w[i1] : 0u;
-                }
+                const uint64_t om = __ballot(first);
+                if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
+                n_o += (uint32_t)__popcll(om);
+                off[t] += n_in;
+                if (off[t] < 64u) break;
+                // chunk used up: the next two are in registers already, request the one after them
+                u0[t] = u1[t]; w0[t] = w1[t];
+                u1[t] = u2[t]; w1[t] = w2[t];
+                pos[t] += 64u;
+                off[t] = 0;
+                load_chunk(t, pos[t] + 128u, 0u, u2[t], w2[t]);
                 __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_wave_barrier();
         }
 
         // harvest: every doc id touched in this window, 64 per step
@@ -424,7 +420,8 @@ void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t s
     if (n_fast) {
         dim3 grid(n_fast), block(64);
         if (a.k <= 64) {
-            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<128, 1024>), grid, block, 0, st, a);
+            if (window <= 512) hipLaunchKernelGGL((k_score_fast<128, 512>), grid, block, 0, st, a);
+            else if (window <= 1024) hipLaunchKernelGGL((k_score_fast<128, 1024>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_score_fast<128, 2048>), grid, block, 0, st, a);
         } else if (a.k <= 256) {
             if (window <= 1024) hipLaunchKernelGGL((k_score_fast<512, 1024>), grid, block, 0, st, a);

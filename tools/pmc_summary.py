@@ -4,7 +4,7 @@ import collections, csv, glob, re, sys
 
 path = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
-f = glob.glob(path + "/*/*counter_collection.csv")[0]
+f = (glob.glob(path + "/*/*counter_collection.csv") + glob.glob(path + "/*counter_collection.csv"))[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     m = re.search(r"(k_[a-z_0-9]+(<[^>]*>)?)", r["Kernel_Name"])
