@@ -180,7 +180,9 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
  * Copies the CSR out (any pointer may be NULL): for term t, web postings are
  * [row_ptr[t], news_ptr[t]) and news postings [news_ptr[t], row_ptr[t+1]), each in ascending
  * unit order.  row_ptr has n_terms + 1 entries, news_ptr n_terms, post_* n_postings;
- * post_weight_tenths is the posting weight times ten (an exact integer).
+ * post_weight_tenths is the posting weight times ten (an exact integer).  row_ptr and news_ptr
+ * must be host arrays.  This is an export call: the index itself keeps one slot per sorted row,
+ * and the compaction into this CSR runs on the host (O(n_rows) time and host memory).
  */
 int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit,
                         uint32_t* post_weight_tenths);
