@@ -158,3 +158,34 @@ def test_long_runs_and_huge_tf_take_the_exact_path(gpu_index_factory):
     ix = gpu_index_factory()
     gpu_build(ix, c2, word_count=None, unit_major=False)
     assert_build_matches(ix, orc)
+
+
+def _random_unit_major_rows(rng, n_rows, n_terms, n_docs, n_articles):
+    """n_rows rows in unit-major order (web docs first, then news articles), several rows per unit,
+    some (term, unit) pairs repeated across fields."""
+    n_news = n_rows // 7 if n_articles else 0
+    n_web = n_rows - n_news
+    unit_web = np.sort(rng.integers(0, n_docs, n_web)).astype(np.uint32)
+    unit_news = np.sort(rng.integers(0, max(n_articles, 1), n_news)).astype(np.uint32)
+    # a skewed term distribution: many repeats of small ids, a long tail
+    term = np.minimum((n_terms * rng.random(n_rows) ** 3).astype(np.uint32), n_terms - 1)
+    tf = rng.integers(1, 40, n_rows).astype(np.uint32)
+    field = rng.choice(np.array([1, 2, 4], np.uint8), n_rows)
+    meta = np.concatenate([se.SRC_WEB | (field[:n_web] << 2), np.full(n_news, se.SRC_NEWS | (4 << 2), np.uint8)]).astype(np.uint8)
+    return dict(term_id=term, unit_id=np.concatenate([unit_web, unit_news]), tf=tf, meta=meta, n_terms=n_terms,
+                n_docs=n_docs, n_articles=n_articles, word_count=None)
+
+
+@pytest.mark.parametrize("n_terms", [5, 1500, 300_000])
+def test_row_counts_around_tile_chunk_and_group_edges(gpu_index_factory, n_terms):
+    """Row counts just below, at and above the sizes the kernels are tiled by (64-row rounds, 512-row
+    batches, 4096-row tiles, 2-tile chunks, 16-chunk groups), with one, two and two-wide sort passes."""
+    rng = np.random.default_rng(n_terms)
+    ix = gpu_index_factory()
+    for n_rows in (1, 2, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193, 12289, 65535, 65536, 65537,
+                   131071, 131073, 200_003):
+        c = _random_unit_major_rows(rng, n_rows, n_terms, n_docs=max(3, n_rows // 9), n_articles=max(2, n_rows // 50))
+        orc = oracle_index(c, word_count=None)
+        gpu_build(ix, c, word_count=None)
+        assert_build_matches(ix, orc)
+        orc.close()
