@@ -30,7 +30,7 @@ struct sebm25_index {
     RowFmt fmt{1, 1, 59};
     uint32_t n_pass = 0;
     int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
-    int score_window = 512;         // unit ids per scoring window (tuning knob: SEBM25_SCORE_WINDOW = 512 | 1024 | 2048)
+    int score_window = 0;           // 0: posting-space steps with hashed accumulators; 512 | 1024 | 2048: unit-id windows of that size (SEBM25_SCORE_WINDOW)
     uint64_t P = 0, P_web = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
     sebm25_doc_totals local_totals{}, used_totals{};
@@ -391,7 +391,7 @@ int sebm25_create(int device, sebm25_index** out) {
     sebm25_index* ix = new (std::nothrow) sebm25_index();
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
-    if (const char* e = getenv("SEBM25_SCORE_WINDOW")) ix->score_window = atoi(e) > 1024 ? 2048 : atoi(e) > 512 ? 1024 : 512;
+    if (const char* e = getenv("SEBM25_SCORE_WINDOW")) ix->score_window = atoi(e) > 1024 ? 2048 : atoi(e) > 512 ? 1024 : atoi(e) > 0 ? 512 : 0;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     *out = ix;
     return SEBM25_OK;

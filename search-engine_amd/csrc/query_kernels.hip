@@ -387,6 +387,154 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
+// Fast path in posting space.  Instead of windows of unit ids (whose lanes are mostly idle when the
+// lists are sparse: a 512-unit window holds about 14 postings of a typical list), a step takes,
+// from every list, all slots up to a frontier F = the smallest "last unit of the chunk in
+// registers" over the lists.  Every posting of a unit <= F is then in this step, whichever list
+// it is in, so the step's sums are final; the list that sets F uses all 64 lanes.  Units are
+// accumulated in a small open-addressing hash table in LDS (at most FAST_T x 64 distinct units per
+// step), lists in query-term order, so a score is the same double sum as on every other path.
+constexpr int HASH_SLOTS = 512;
+constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
+
+template <int CAP>
+__global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
+    __shared__ __align__(16) double acc[HASH_SLOTS];
+    __shared__ uint32_t tag[HASH_SLOTS];
+    __shared__ unsigned char cnt[HASH_SLOTS];
+    __shared__ unsigned short used[FAST_T * 64];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+
+    const QItem it = a.items[blockIdx.x];
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t T = it.n_terms;
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+
+    uint32_t my_cur = 0, my_end = 0;
+    double my_idf = 0.0;
+    if (lane < T) {
+        const uint32_t term = a.q_terms[it.term_off + lane];
+        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
+        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
+    }
+    // per list: slot index of the current chunk's lane 0, first unconsumed lane of that chunk, end
+    // of the list, and three aligned chunks of units / weights (slots outside [cursor, end) read INF)
+    uint32_t pos[FAST_T], off[FAST_T], end[FAST_T];
+    uint32_t u0[FAST_T], u1[FAST_T], u2[FAST_T], w0[FAST_T], w1[FAST_T], w2[FAST_T];
+    double idf[FAST_T];
+    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& u, uint32_t& w) {
+        const uint32_t i = p + lane;
+        const bool ok = i >= lo && i < end[t];
+        u = ok ? a.post_unit[i] : INF;
+        w = ok ? a.post_w[i] : POST_HOLE;
+    };
+#pragma unroll
+    for (int t = 0; t < FAST_T; ++t) {
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
+        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
+        idf[t] = readlane_f64(my_idf, t);
+        pos[t] = cur & ~63u;
+        off[t] = cur & 63u;
+        if (cur >= end[t]) {  // empty list (or t >= T): nothing to read
+            pos[t] = 0;
+            off[t] = 0;
+            end[t] = 0;
+        }
+        load_chunk(t, pos[t], cur, u0[t], w0[t]);
+        load_chunk(t, pos[t] + 64u, cur, u1[t], w1[t]);
+        load_chunk(t, pos[t] + 128u, cur, u2[t], w2[t]);
+    }
+    for (uint32_t x = lane; x < HASH_SLOTS; x += 64) tag[x] = HASH_EMPTY;
+    TopK<CAP> tk;
+    tk.init(topk_mem);
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        // frontier: the smallest last unit of the chunks at hand (INF for a list whose rest is in registers)
+        uint32_t frontier = INF, any = INF;
+#pragma unroll
+        for (int t = 0; t < FAST_T; ++t) {
+            if ((uint32_t)t < T) {
+                any = min(any, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], (int)off[t]));
+                frontier = min(frontier, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], 63));
+            }
+        }
+        if (any == INF) break;  // every list is used up
+
+        uint32_t n_used = 0;
+#pragma unroll
+        for (int t = 0; t < FAST_T; ++t) {
+            if ((uint32_t)t >= T) break;
+            const bool in = lane >= off[t] && u0[t] != INF && u0[t] <= frontier;
+            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+            bool fresh = false;
+            uint32_t h = 0;
+            if (in && w0[t] != POST_HOLE) {  // a hole only moves the cursor
+                const uint32_t u = u0[t];
+                const double v = __dmul_rn(idf[t], (double)w0[t]);
+                h = (u * 2654435761u) >> 23;  // 9 bits: HASH_SLOTS = 512
+                while (true) {
+                    const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, u);
+                    if (old == HASH_EMPTY) {
+                        fresh = true;
+                        break;
+                    }
+                    if (old == u) break;
+                    h = (h + 1u) & (HASH_SLOTS - 1u);
+                }
+                if (fresh) {
+                    acc[h] = v;
+                    cnt[h] = 1;
+                } else {
+                    acc[h] = __dadd_rn(acc[h], v);
+                    cnt[h] = (unsigned char)(cnt[h] + 1);
+                }
+            }
+            const uint64_t fm = __ballot(fresh);
+            if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
+            n_used += (uint32_t)__popcll(fm);
+            off[t] += n_in;
+            if (off[t] >= 64u) {
+                // chunk used up: the next two are in registers already, request the one after them
+                u0[t] = u1[t]; w0[t] = w1[t];
+                u1[t] = u2[t]; w1[t] = w2[t];
+                pos[t] += 64u;
+                off[t] = 0;
+                load_chunk(t, pos[t] + 128u, 0u, u2[t], w2[t]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // harvest: every unit of this step, 64 per round; the table is left empty again
+        for (uint32_t o0 = 0; o0 < n_used; o0 += 64) {
+            const bool has = o0 + lane < n_used;
+            double s = 0.0;
+            uint32_t m = 0, unit = 0, tie = 0;
+            if (has) {
+                const uint32_t h = used[o0 + lane];
+                s = acc[h];
+                m = cnt[h];
+                unit = tag[h];
+                tag[h] = HASH_EMPTY;
+                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+            }
+            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const size_t o = (size_t)it.out_slot * a.k;
+    if (it.direct)
+        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                     a.out_count + it.out_slot);
+    else
+        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+}
+
 // one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
 template <int CAP>
 __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
@@ -417,7 +565,12 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 
 // items [0, n_fast) have at most FAST_T lists, the rest use the general kernel
 void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st) {
-    if (n_fast) {
+    if (n_fast && window == 0) {  // posting-space steps with hashed accumulators
+        dim3 grid(n_fast), block(64);
+        if (a.k <= 64) hipLaunchKernelGGL(k_score_hash<128>, grid, block, 0, st, a);
+        else if (a.k <= 256) hipLaunchKernelGGL(k_score_hash<512>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(k_score_hash<4096>, grid, block, 0, st, a);
+    } else if (n_fast) {
         dim3 grid(n_fast), block(64);
         if (a.k <= 64) {
             if (window <= 512) hipLaunchKernelGGL((k_score_fast<128, 512>), grid, block, 0, st, a);
