@@ -39,7 +39,7 @@ struct sebm25_index {
 
     DevBuf sortA, sortB, chunk_hist, group_off, bin_start, scan_tmp;
     DevBuf row_ptr, news_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
-    DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc, 5 kept web postings; u32 err at [7]; then the dump words
+    DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc, 5 kept web postings; u32 err at [7]
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
     DevBuf url_rank_web, url_rank_news;
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
@@ -224,7 +224,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
     HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
     HIP_TRY(ix, ix->doc_len.ensure(std::max<size_t>(in->n_docs, 1) * 4));
-    HIP_TRY(ix, ix->scalars.ensure(64 + (size_t)DUMP_WORDS * 8));
+    HIP_TRY(ix, ix->scalars.ensure(64));
     HIP_TRY(ix, hipMemsetAsync(ix->scalars.p, 0, 64, ix->stream));
     HIP_TRY(ix, hipMemsetAsync(ix->doc_len.p, 0, std::max<size_t>(in->n_docs, 1) * 4, ix->stream));
     uint64_t* scal = ix->scalars.as<uint64_t>();
@@ -261,14 +261,9 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         const int key_bits = 64 - key_lo;
         const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
         ix->n_pass = (uint32_t)n_pass;
-        // Rows per chunk, by pass: the more bins a pass has, the shorter a tile's run per bin and the more
-        // it matters that neighbouring runs are written at about the same time, so the widest digits
-        // take one tile per chunk.  SEBM25_SORT_CHUNK_TILES (1..8) overrides, for experiments.
-        const int forced_tiles = getenv("SEBM25_SORT_CHUNK_TILES") ? std::min(8, std::max(1, atoi(getenv("SEBM25_SORT_CHUNK_TILES")))) : 0;
-        auto chunk_rows_of = [&](int bits) -> uint64_t {
-            return (uint64_t)(forced_tiles ? forced_tiles : (bits >= SORT_MAX_BITS ? 1 : SORT_CHUNK_TILES)) * SORT_TILE;
-        };
-        const uint32_t G = (uint32_t)((R + SORT_TILE - 1) / SORT_TILE);  // most chunks any pass can have
+        // one chunk = one tile = the work of one scatter workgroup
+        const uint64_t chunk_rows = SORT_TILE;
+        const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
         const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
         HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 4));
         HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
@@ -282,7 +277,6 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         if (ctx.debug & 4u) ctx.check_order = 0;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
         ctx.err = err_dev;
-        ctx.dump = scal + 8;
 
         static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6"};
         static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6"};
@@ -295,9 +289,6 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
             const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
             const int mode = p == 0 ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
             uint64_t* dst = bufs[p & 1];
-            const uint64_t chunk_rows = chunk_rows_of(bits);
-            const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
-            const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
             uint32_t* prefix = ix->chunk_hist.as<uint32_t>();
             uint32_t* group_off = ix->group_off.as<uint32_t>();
             uint32_t* bin_start = ix->bin_start.as<uint32_t>();
@@ -308,7 +299,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
             launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->stream);
             phase_end(ix);
             phase_begin(ix, scat_names[p]);
-            launch_sort_scatter(mode, raw, src_packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start, ix->stream);
+            launch_sort_scatter(mode, raw, src_packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start, ix->stream);
             phase_end(ix);
             src_packed = dst;
             shift += bits;

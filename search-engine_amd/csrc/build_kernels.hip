@@ -62,8 +62,8 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ------------------------------------------------------------------ histogram (upsweep) ---
-// Rows are cut into chunks of SORT_CHUNK_TILES tiles, chunks into groups of SORT_GROUP.  A
-// workgroup counts the digits of the chunks of one group, one chunk after the other, and writes
+// Rows are cut into chunks of one tile (SORT_TILE rows), chunks into groups of SORT_GROUP.  A
+// workgroup counts the digits of the chunks of one group, one wavefront per chunk, and writes
 // for every chunk the counts of the group's earlier chunks (prefix[chunk][bin], coalesced) and at
 // the end the group's totals (group_tot[group][bin]).  A chunk's write base for a bin is then
 //   bin_base[bin] + group_off[group][bin] + prefix[chunk][bin]
@@ -233,45 +233,32 @@ __global__ __launch_bounds__(256) void k_sort_group_scan(uint32_t* group_tot, ui
     if (lane == 0) bin_tot[b] = carry;
 }
 
-// ------------------------------------------------------------------ scatter (downsweep) ---
-#ifdef SEBM25_PHASE_STAMPS
-// Diagnostic build only: per-workgroup cycle totals of each tile phase of the scatter kernels.
-__device__ unsigned long long g_stamps[3][1024][8];
-#define STAMP(k)                                                                  \
-    do {                                                                          \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime();            \
-        if (threadIdx.x == 0) g_stamps[MODE][blockIdx.x & 1023][k] += now__ - t_prev; \
-        t_prev = now__;                                                           \
-    } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
-
 constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-length counters
 
+// ------------------------------------------------------------------ scatter (downsweep) ---
 // MODE 0: raw rows, digit inside the term bits (unit-major input: the usual first pass)
 // MODE 1: raw rows, digit anywhere in the packed key (first pass of a (term, source, unit) sort)
 // MODE 2: packed rows
 // Raw rows are validated, packed and their body lengths accumulated on the way through.
 //
-// The tile loop is software-pipelined around the vector-memory counter, which retires loads and
-// stores in issue order: the loads of the NEXT tile are issued after the current tile has been
-// reordered in LDS (its registers are free then) and BEFORE its stores, and both the loads and
-// the stores of a tile are unconditional and fixed in number (rows past the end read a clamped
-// address and write a dump word).  The wait at the top of the next tile can therefore leave the
-// stores in flight instead of draining them.
+// One tile (= one chunk) per workgroup: no tile loop, so the raw columns are only live until the
+// rows are packed and the kernel fits 80 vector registers; the digit-match tables and the
+// body-length counters share the LDS of the tile buffer (they are dead before the tile is
+// reordered into it).  52 KB of LDS and 80 registers put three workgroups on a CU, which is what
+// hides the latency of a tile's phases (load, rank, offsets, reorder, store); a looped form with
+// the next tile's loads issued ahead of the stores, two workgroups per CU, was 45 % slower.
 template <int MODE>
-__global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, const uint64_t* packed, uint64_t* dst,
-                                                               uint64_t R, uint64_t chunk_rows, uint32_t G, int shift,
-                                                               int bits, BuildCtx ctx, const uint32_t* prefix,
-                                                               const uint32_t* group_off, const uint32_t* bin_start) {
+__global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows raw, const uint64_t* packed, uint64_t* dst,
+                                                                    uint64_t R, uint32_t G, int shift, int bits,
+                                                                    BuildCtx ctx, const uint32_t* prefix,
+                                                                    const uint32_t* group_off, const uint32_t* bin_start) {
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
-    __shared__ uint32_t mtab[SORT_WAVES][2 << MATCH_TAB_BITS];  // per wave: lane masks per folded digit
-    __shared__ uint64_t rows_s[SORT_TILE];                      // the tile, locally ordered by digit
-    __shared__ uint32_t delta[SORT_MAX_BINS];     // global slot minus local slot, per digit, this tile
-    __shared__ uint32_t bin_base[SORT_MAX_BINS];  // next global slot of each digit for this chunk
+    __shared__ __align__(16) uint64_t rows_s[SORT_TILE];                       // the tile, locally ordered by digit
+    __shared__ uint32_t base[SORT_MAX_BINS];  // first the chunk's write base per digit, then global minus local slot
     __shared__ uint32_t wave_tot[SORT_WAVES];
-    __shared__ uint32_t dl_s[DL_SPAN];            // body length per doc of this tile
+    uint32_t* mtab = reinterpret_cast<uint32_t*>(rows_s);     // per wave: lane masks per folded digit (16 KB)
+    uint32_t* dl_s = mtab + SORT_WAVES * (2u << MATCH_TAB_BITS);  // body length per doc of this tile (2 KB)
+    static_assert(SORT_WAVES * (2u << MATCH_TAB_BITS) * 4 + DL_SPAN * 4 <= SORT_TILE * 8, "aliases fit the tile buffer");
 
     const RowFmt fmt = ctx.fmt;
     const uint32_t nb = 1u << bits, mask = nb - 1u;
@@ -282,255 +269,220 @@ __global__ __launch_bounds__(SORT_THREADS, 4) void k_sort_scatter(RawRows raw, c
     const uint32_t per_xcd = (G + 7u) / 8u;
     const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (chunk >= G) return;
-    const uint64_t begin = (uint64_t)chunk * chunk_rows;
-    const uint64_t end = min(R, begin + chunk_rows);
-    if (begin >= end) return;
+    const uint64_t tile0 = (uint64_t)chunk * SORT_TILE;
+    const uint64_t end = min(R, tile0 + SORT_TILE);
+    const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;  // wave w owns 8 rounds of 64 rows
     uint32_t* wh32 = reinterpret_cast<uint32_t*>(&whist[0][0]);  // two 16-bit counters per word
-    for (uint32_t d = t; d < nb; d += SORT_THREADS)
-        bin_base[d] = bin_start[d] + group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
-    for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
-    for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS); x += SORT_THREADS) (&mtab[0][0])[x] = 0;
-    if (MODE != 2) dl_s[t] = 0;
-    __syncthreads();
 
     uint64_t row[SORT_ITEMS];
     uint32_t term[SORT_ITEMS], unit[SORT_ITEMS], tfv[SORT_ITEMS], m[SORT_ITEMS];  // raw columns (MODE 0, 1)
     uint32_t prev_u = 0, prev_m = 0, first_u = 0, first_m = 0;  // row before this wave's rows; first row of the tile
-    // wave w owns rows [tile + w*64*ITEMS, +64*ITEMS) of a tile, 64 consecutive rows per round
-    auto load_tile = [&](uint64_t t0) {
-        const uint64_t w0 = t0 + (uint64_t)wave * 64u * SORT_ITEMS;
 #pragma unroll
-        for (int j = 0; j < SORT_ITEMS; ++j) {
-            const uint64_t i = min(w0 + (uint64_t)j * 64u + lane, end - 1);
-            if (MODE == 2) {
-                row[j] = packed[i];
-            } else {
-                term[j] = raw.term[i];
-                unit[j] = raw.unit[i];
-                tfv[j] = raw.tf[i];
-                m[j] = raw.meta[i];
-            }
-        }
-        if (MODE != 2) {
-            const uint64_t ip = min(w0 ? w0 - 1 : 0, end - 1), i0 = min(t0, end - 1);
-            prev_u = raw.unit[ip];
-            prev_m = raw.meta[ip];
-            first_u = raw.unit[i0];
-            first_m = raw.meta[i0];
-        }
-    };
-    load_tile(begin);
-    // as many stores behind the first tile's loads as behind every later tile's
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) ctx.dump[j * 64 + lane] = 0ull;
-#ifdef SEBM25_PHASE_STAMPS
-    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#endif
-
-    for (uint64_t tile0 = begin; tile0 < end; tile0 += SORT_TILE) {
-        const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;
-        uint32_t tile_u_first = 0;
-        bool tile_web = false;
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const uint64_t i = min(wave0 + (uint64_t)j * 64u + lane, end - 1);
         if (MODE == 2) {
-#pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j)
-                if (wave0 + (uint64_t)j * 64u + lane >= end) row[j] = ~0ull;
+            row[j] = packed[i];
         } else {
-            // validate and pack the raw rows, check unit-major order, accumulate body lengths
-            tile_u_first = first_u;
-            tile_web = (first_m & 3u) == SEBM25_SRC_WEB;
-            // (source, unit) of the row before this wave's first row
-            uint64_t carry = wave0 > 0 ? (((uint64_t)(((prev_m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | prev_u) : 0ull;
-#pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) {
-                const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-                const bool valid = i < end;
-                const uint32_t st = m[j] & 3u, field = m[j] >> 2;
-                const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
-                uint64_t r = ~0ull;
-                if (valid) {
-                    const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
-                                     unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
-                                     (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
-                    if (bad) {
-                        atomicOr(ctx.err, DEV_ERR_RANGE);
-                        // the same key bits as the histogram saw, every later index in range
-                        term[j] = min(term[j], ctx.n_terms - 1u);
-                        unit[j] &= (uint32_t)((1ull << fmt.unit_bits) - 1ull);
-                        tfv[j] = 0;
-                    }
-                    r = fmt.pack(term[j], src, unit[j], field_code(field), tfv[j]);
-                }
-                row[j] = r;
-                // unit-major check: (source, unit) must not decrease from one row to the next
-                const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit[j]) : ~0ull;
-                uint64_t prev = lane_up1(ukey);
-                if (lane == 0) prev = carry;
-                carry = lane_bcast<63>(ukey);
-                if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
-                // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
-                // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
-                const uint32_t body = (!(ctx.debug & 1u) && valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
-                const uint64_t first_key = lane_bcast<0>(ukey);
-                const bool uniform = __all(ukey == first_key);
-                uint32_t add = body;
-                bool do_add = body != 0u;
-                if (uniform) {
-                    add = wave_sum_u32(body);
-                    do_add = lane == 0 && add != 0u;
-                }
-                if (do_add) {
-                    const uint32_t off = unit[j] - tile_u_first;
-                    if (tile_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
-                        atomicAdd(&dl_s[off], add);
-                    else
-                        atomicAdd(&ctx.doc_len[unit[j]], add);
-                }
-            }
+            term[j] = raw.term[i];
+            unit[j] = raw.unit[i];
+            tfv[j] = raw.tf[i];
+            m[j] = raw.meta[i];
         }
-        STAMP(0);  // rows available and packed
+    }
+    if (MODE != 2) {
+        const uint64_t ip = min(wave0 ? wave0 - 1 : 0, end - 1);
+        prev_u = raw.unit[ip];
+        prev_m = raw.meta[ip];
+        first_u = raw.unit[tile0];
+        first_m = raw.meta[tile0];
+    }
+    for (uint32_t d = t; d < nb; d += SORT_THREADS)
+        base[d] = bin_start[d] + group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
+    for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
+    for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS) + DL_SPAN; x += SORT_THREADS) mtab[x] = 0;
+    __syncthreads();
 
-        // ---- rank: position of each row among the rows of its digit held by this wave.
-        // The lanes that share a digit are found through the wave's LDS table (see MATCH_TAB_BITS),
-        // for all rounds at once: a wave's LDS operations execute in issue order, so round j + 1
-        // may mark its slots before round j's masks have come back, as long as every lane that marked
-        // a slot also clears it again.  Only then are the masks waited for, once.
-        uint32_t rk[SORT_ITEMS];
-        {
-            uint32_t* tab = mtab[wave];
-            uint32_t dg[SORT_ITEMS];
-            uint64_t cand[SORT_ITEMS], m0[SORT_ITEMS];
-            uint32_t in0_bits = 0, valid_bits = 0;
+    uint32_t tile_u_first = 0;
+    bool tile_web = false;
+    if (MODE == 2) {
 #pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) {
-                const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-                const bool valid = i < end;
-                const uint32_t d = shr_lo32(row[j], shift) & mask;
-                dg[j] = d;
-                const uint64_t vm = __ballot(valid);
-                // the group of the first valid lane (the hot digit of skewed or sorted rows) by one compare
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, vm ? __ffsll((unsigned long long)vm) - 1 : 0);
-                const bool in0 = valid && d == d0;
-                m0[j] = __ballot(in0);
-                const bool rest = valid && !in0;
-                valid_bits |= (valid ? 1u : 0u) << j;
-                in0_bits |= (in0 ? 1u : 0u) << j;
-                const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
-                cand[j] = 0;
-                if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
-                __builtin_amdgcn_wave_barrier();
-                if (rest) cand[j] = *reinterpret_cast<const uint64_t*>(&tab[slot]);
-                __builtin_amdgcn_wave_barrier();
-                if (rest) *reinterpret_cast<uint64_t*>(&tab[slot]) = 0ull;
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int j = 0; j < SORT_ITEMS; ++j) {
-                const bool valid = (valid_bits >> j) & 1u;
-                uint64_t peers = cand[j];  // lanes that share the low digit bits: settle the high bits
-                for (int b = MATCH_TAB_BITS; b < bits; ++b) {
-                    const bool one = (dg[j] >> b) & 1u;
-                    const uint64_t bal = __ballot(one);
-                    peers &= one ? bal : ~bal;
+        for (int j = 0; j < SORT_ITEMS; ++j)
+            if (wave0 + (uint64_t)j * 64u + lane >= end) row[j] = ~0ull;
+    } else {
+        // validate and pack the raw rows, check unit-major order, accumulate body lengths
+        tile_u_first = first_u;
+        tile_web = (first_m & 3u) == SEBM25_SRC_WEB;
+        // (source, unit) of the row before this wave's first row
+        uint64_t carry = wave0 > 0 ? (((uint64_t)(((prev_m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | prev_u) : 0ull;
+    #pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
+            const bool valid = i < end;
+            const uint32_t st = m[j] & 3u, field = m[j] >> 2;
+            const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
+            uint64_t r = ~0ull;
+            if (valid) {
+                const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
+                                 unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
+                                 (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
+                if (bad) {
+                    atomicOr(ctx.err, DEV_ERR_RANGE);
+                    // the same key bits as the histogram saw, every later index in range
+                    term[j] = min(term[j], ctx.n_terms - 1u);
+                    unit[j] &= (uint32_t)((1ull << fmt.unit_bits) - 1ull);
+                    tfv[j] = 0;
                 }
-                if ((in0_bits >> j) & 1u) peers = m0[j];
-                // every lane of a digit group reads the group's running count (one address: a broadcast),
-                // then its first lane adds the group's size
-                uint32_t old = 0;
-                if (valid) old = whist[wave][dg[j]];
-                __builtin_amdgcn_wave_barrier();
-                if (valid && (peers & lanemask_lt()) == 0) whist[wave][dg[j]] = (unsigned short)(old + (uint32_t)__popcll(peers));
-                rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
-                __builtin_amdgcn_wave_barrier();
+                r = fmt.pack(term[j], src, unit[j], field_code(field), tfv[j]);
+            }
+            row[j] = r;
+            // unit-major check: (source, unit) must not decrease from one row to the next
+            const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit[j]) : ~0ull;
+            uint64_t prev = lane_up1(ukey);
+            if (lane == 0) prev = carry;
+            carry = lane_bcast<63>(ukey);
+            if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
+            // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
+            // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
+            const uint32_t body = (!(ctx.debug & 1u) && valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
+            const uint64_t first_key = lane_bcast<0>(ukey);
+            const bool uniform = __all(ukey == first_key);
+            uint32_t add = body;
+            bool do_add = body != 0u;
+            if (uniform) {
+                add = wave_sum_u32(body);
+                do_add = lane == 0 && add != 0u;
+            }
+            if (do_add) {
+                const uint32_t off = unit[j] - tile_u_first;
+                if (tile_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
+                    atomicAdd(&dl_s[off], add);
+                else
+                    atomicAdd(&ctx.doc_len[unit[j]], add);
             }
         }
-        STAMP(1);  // ranked
-        __syncthreads();
-        STAMP(2);  // barrier
 
-        // ---- per digit pair (2t, 2t+1): exclusive offsets over the waves and the tile counts, two
-        //      16-bit counters per LDS word; then a block scan of the counts held in registers
-        uint32_t c0 = 0, c1 = 0;
-        if (2 * t < nb) {
-            uint32_t c[SORT_WAVES];
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
-            uint32_t run = 0;  // packed: neither half can carry (a tile has at most 4096 rows)
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) {
-                const uint32_t x = c[w];
-                c[w] = run;
-                run += x;
-            }
-            c0 = run & 0xFFFFu;
-            c1 = run >> 16;
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w];
-        }
-        if (MODE != 2) {
-            const uint32_t v = dl_s[t];
-            if (v) {
-                atomicAdd(&ctx.doc_len[tile_u_first + t], v);
-                dl_s[t] = 0;
-            }
-        }
-        uint32_t inc = c0 + c1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t x = __shfl_up(inc, off);
-            if ((int)lane >= off) inc += x;
-        }
-        if (lane == 63) wave_tot[wave] = inc;
-        __syncthreads();
-        if (2 * t < nb) {
-            uint32_t ts0 = inc - (c0 + c1);
-            for (uint32_t w = 0; w < wave; ++w) ts0 += wave_tot[w];
-            const uint32_t ts1 = ts0 + c0;
-            // global slot of local slot p of digit d: delta[d] + p (32-bit wrap-around arithmetic)
-            delta[2 * t] = bin_base[2 * t] - ts0;
-            bin_base[2 * t] += c0;
-            delta[2 * t + 1] = bin_base[2 * t + 1] - ts1;
-            bin_base[2 * t + 1] += c1;
-            const uint32_t add = ts0 | (ts1 << 16);  // per-wave offsets become local slots
-            uint32_t c[SORT_WAVES];
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w] + add;
-        }
-        __syncthreads();
-        STAMP(3);  // offsets
+    }
 
-        // ---- reorder the tile by digit inside LDS (stable)
-        const uint32_t n_tile = (uint32_t)min((uint64_t)SORT_TILE, end - tile0);
+    uint32_t rk[SORT_ITEMS];
+    {
+        uint32_t* tab = mtab + wave * (2u << MATCH_TAB_BITS);
+        uint32_t dg[SORT_ITEMS];
+        uint64_t cand[SORT_ITEMS], m0[SORT_ITEMS];
+        uint32_t in0_bits = 0, valid_bits = 0;
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-            if (i < end) {
-                const uint32_t d = (uint32_t)(row[j] >> shift) & mask;
-                rows_s[whist[wave][d] + rk[j]] = row[j];
-            }
+            const bool valid = i < end;
+            const uint32_t d = shr_lo32(row[j], shift) & mask;
+            dg[j] = d;
+            const uint64_t vm = __ballot(valid);
+            // the group of the first valid lane (the hot digit of skewed or sorted rows) by one compare
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, vm ? __ffsll((unsigned long long)vm) - 1 : 0);
+            const bool in0 = valid && d == d0;
+            m0[j] = __ballot(in0);
+            const bool rest = valid && !in0;
+            valid_bits |= (valid ? 1u : 0u) << j;
+            in0_bits |= (in0 ? 1u : 0u) << j;
+            const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
+            cand[j] = 0;
+            if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
+            __builtin_amdgcn_wave_barrier();
+            if (rest) cand[j] = *reinterpret_cast<const uint64_t*>(&tab[slot]);
+            __builtin_amdgcn_wave_barrier();
+            if (rest) *reinterpret_cast<uint64_t*>(&tab[slot]) = 0ull;
+            __builtin_amdgcn_wave_barrier();
         }
-        load_tile(tile0 + SORT_TILE);  // next tile (clamped addresses behind the chunk's end)
-        __syncthreads();
-        STAMP(4);  // reordered
-
-        // ---- write out: consecutive threads hold consecutive slots of a digit's run
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
-            const uint32_t p = t + (uint32_t)j * SORT_THREADS;
+            const bool valid = (valid_bits >> j) & 1u;
+            uint64_t peers = cand[j];  // lanes that share the low digit bits: settle the high bits
+            for (int b = MATCH_TAB_BITS; b < bits; ++b) {
+                const bool one = (dg[j] >> b) & 1u;
+                const uint64_t bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            if ((in0_bits >> j) & 1u) peers = m0[j];
+            // every lane of a digit group reads the group's running count (one address: a broadcast),
+            // then its first lane adds the group's size
+            uint32_t old = 0;
+            if (valid) old = whist[wave][dg[j]];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (peers & lanemask_lt()) == 0) whist[wave][dg[j]] = (unsigned short)(old + (uint32_t)__popcll(peers));
+            rk[j] = old + (uint32_t)__popcll(peers & lanemask_lt());
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+
+    // ---- per digit pair (2t, 2t+1): exclusive offsets over the waves and the tile counts, two
+    //      16-bit counters per LDS word; then a block scan of the counts held in registers
+    uint32_t c0 = 0, c1 = 0;
+    if (2 * t < nb) {
+        uint32_t c[SORT_WAVES];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
+        uint32_t run = 0;  // packed: neither half can carry (a tile has at most 4096 rows)
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t x = c[w];
+            c[w] = run;
+            run += x;
+        }
+        c0 = run & 0xFFFFu;
+        c1 = run >> 16;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w];
+    }
+    if (MODE != 2) {
+        const uint32_t v = dl_s[t];
+        if (v) atomicAdd(&ctx.doc_len[tile_u_first + t], v);
+    }
+    uint32_t inc = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += x;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    if (2 * t < nb) {
+        uint32_t ts0 = inc - (c0 + c1);
+        for (uint32_t w = 0; w < wave; ++w) ts0 += wave_tot[w];
+        const uint32_t ts1 = ts0 + c0;
+        // global slot of local slot p of digit d: base[d] + p (32-bit wrap-around arithmetic)
+        base[2 * t] -= ts0;
+        base[2 * t + 1] -= ts1;
+        const uint32_t add = ts0 | (ts1 << 16);  // per-wave offsets become local slots
+        uint32_t c[SORT_WAVES];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) c[w] = wh32[w * (SORT_MAX_BINS / 2) + t];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) wh32[w * (SORT_MAX_BINS / 2) + t] = c[w] + add;
+    }
+    __syncthreads();
+
+    // ---- reorder the tile by digit inside LDS (stable); the match tables and body-length counters
+    //      that shared this memory are dead by now
+    const uint32_t n_tile = (uint32_t)(end - tile0);
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
+        if (i < end) {
+            const uint32_t d = shr_lo32(row[j], shift) & mask;
+            rows_s[whist[wave][d] + rk[j]] = row[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- write out: consecutive threads hold consecutive slots of a digit's run
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const uint32_t p = t + (uint32_t)j * SORT_THREADS;
+        if (p < n_tile) {
             const uint64_t r = rows_s[p];
-            const uint32_t d = (uint32_t)(r >> shift) & mask;
-            uint64_t* out = p < n_tile ? dst + (uint32_t)(delta[d] + p) : ctx.dump + lane;
-            *out = r;
+            const uint32_t d = shr_lo32(r, shift) & mask;
+            dst[(uint32_t)(base[d] + p)] = r;
         }
-        {
-            uint4* z = reinterpret_cast<uint4*>(&whist[0][0]);
-            for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS * 2 / 16; x += SORT_THREADS) z[x] = make_uint4(0, 0, 0, 0);
-        }
-        STAMP(5);  // stores issued
-        __syncthreads();
-        STAMP(6);  // tile end barrier
     }
 }
 
@@ -554,16 +506,16 @@ void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint3
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bin_tot, (size_t)nb);
 }
 
-void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
-                         uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                         const uint32_t* prefix, const uint32_t* group_off, const uint32_t* bin_start, hipStream_t st) {
+void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
+                         int bits, const BuildCtx& ctx, const uint32_t* prefix, const uint32_t* group_off,
+                         const uint32_t* bin_start, hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_scatter<0>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<0>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_scatter<1>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<1>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
     else
-        hipLaunchKernelGGL(k_sort_scatter<2>, grid, block, 0, st, raw, packed, dst, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<2>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------
@@ -1064,14 +1016,3 @@ void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_t
 }
 
 }  // namespace sebm25
-
-#ifdef SEBM25_PHASE_STAMPS
-extern "C" int sebm25_debug_stamps(unsigned long long* out, int clear) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(sebm25::g_stamps), sizeof(sebm25::g_stamps)) != hipSuccess) return 1;
-    if (clear) {
-        static unsigned long long zero[3][1024][8];
-        if (hipMemcpyToSymbol(HIP_SYMBOL(sebm25::g_stamps), zero, sizeof(zero)) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif

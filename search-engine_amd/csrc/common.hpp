@@ -94,7 +94,6 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SORT_MAX_BITS = 10;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
-constexpr int SORT_CHUNK_TILES = 2;   // tiles per chunk (the unit of work of one scatter workgroup)
 constexpr int SORT_GROUP = 16;        // chunks per histogram workgroup
 
 constexpr int RED_THREADS = 256;
@@ -103,8 +102,6 @@ constexpr int RED_BATCH = 64 * RED_ROUNDS;
 constexpr int POST_PAD = 2 * RED_BATCH;       // slack entries behind each posting slot array
 constexpr uint64_t MAX_ROWS = 0xFFFFF000ull;  // row indices plus a few batches of look-ahead stay 32-bit
 
-constexpr int DUMP_WORDS = 64 * SORT_ITEMS;
-
 struct BuildCtx {
     RowFmt fmt;
     uint32_t n_terms, n_docs, n_articles;
@@ -112,7 +109,6 @@ struct BuildCtx {
     uint32_t debug;         // experiment switches (SEBM25_DEBUG): 1 skip body lengths, 2 skip validation
     uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
     uint32_t* err;          // device error word
-    uint64_t* dump;         // DUMP_WORDS words that absorb the stores of rows behind the end
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) ----
@@ -122,9 +118,9 @@ void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R,
                       int shift, int bits, const BuildCtx& ctx, uint32_t* prefix /* [G][bins] */,
                       uint32_t* group_tot /* [groups][bins] */, hipStream_t st);
 void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot /* [bins] */, hipStream_t st);
-void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R,
-                         uint64_t chunk_rows, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                         const uint32_t* prefix, const uint32_t* group_off, const uint32_t* bin_start, hipStream_t st);
+void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
+                         int bits, const BuildCtx& ctx, const uint32_t* prefix, const uint32_t* group_off,
+                         const uint32_t* bin_start, hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
