@@ -157,8 +157,8 @@ def main():
     # algorithmic bytes per input row of each build kernel (what it must read + what it must write)
     KERNELS = {
         "sort_hist_0": ("k_sort_hist<0>", 4), "sort_hist_1": ("k_sort_hist<2>", 8),
-        "sort_scatter_0": ("k_sort_scatter<0>", 13 + 8),   # raw row in, packed row out
-        "sort_scatter_1": ("k_sort_scatter<2>", 8 + 8),    # packed row in, packed row out
+        "sort_scatter_0": ("k_sort_scatter_tile<0>", 13 + 8),   # raw row in, packed row out
+        "sort_scatter_1": ("k_sort_scatter_tile<2>", 8 + 8),    # packed row in, packed row out
         "postings": ("k_postings", 8 + 8),                 # packed row in, posting slot out
     }
     dev_ms = sum(ms for _, ms in phases)

@@ -15,7 +15,7 @@ thread_local std::string g_thread_err;
 
 constexpr uint32_t MAX_K = 2048;
 constexpr uint32_t MAX_QUERY_TERMS = 64;
-constexpr uint32_t RED_MAX_CHUNKS = 4096;  // wavefronts
+constexpr uint32_t RED_MAX_CHUNKS = 16384;  // wavefronts
 }  // namespace
 
 struct sebm25_index {

@@ -97,7 +97,7 @@ constexpr int SORT_MAX_BINS = 1 << SORT_MAX_BITS;
 constexpr int SORT_GROUP = 16;        // chunks per histogram workgroup
 
 constexpr int RED_THREADS = 256;
-constexpr int RED_ROUNDS = 8;                 // 64-row rounds a wave loads before it processes them
+constexpr int RED_ROUNDS = 4;                 // 64-row rounds a wave loads before it processes them
 constexpr int RED_BATCH = 64 * RED_ROUNDS;
 constexpr int POST_PAD = 2 * RED_BATCH;       // slack entries behind each posting slot array
 constexpr uint64_t MAX_ROWS = 0xFFFFF000ull;  // row indices plus a few batches of look-ahead stay 32-bit
