@@ -265,7 +265,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         const uint64_t chunk_rows = SORT_TILE;
         const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
         const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
-        HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 4));
+        HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 2));
         HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
         HIP_TRY(ix, ix->bin_start.ensure((size_t)SORT_MAX_BINS * 4));
 
@@ -273,8 +273,6 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ctx.fmt = fmt;
         ctx.n_terms = V; ctx.n_docs = in->n_docs; ctx.n_articles = in->n_articles;
         ctx.check_order = unit_major ? 1u : 0u;
-        ctx.debug = getenv("SEBM25_DEBUG") ? (uint32_t)atoi(getenv("SEBM25_DEBUG")) : 0u;
-        if (ctx.debug & 4u) ctx.check_order = 0;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
         ctx.err = err_dev;
 
@@ -289,7 +287,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
             const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
             const int mode = p == 0 ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
             uint64_t* dst = bufs[p & 1];
-            uint32_t* prefix = ix->chunk_hist.as<uint32_t>();
+            unsigned short* prefix = ix->chunk_hist.as<unsigned short>();
             uint32_t* group_off = ix->group_off.as<uint32_t>();
             uint32_t* bin_start = ix->bin_start.as<uint32_t>();
             phase_begin(ix, hist_names[p]);

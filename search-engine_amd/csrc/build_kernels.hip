@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // ------------------------------------------------------------------ histogram (upsweep) ---
 // Rows are cut into chunks of one tile (SORT_TILE rows), chunks into groups of SORT_GROUP.  A
 // workgroup counts the digits of the chunks of one group, one wavefront per chunk, and writes
-// for every chunk the counts of the group's earlier chunks (prefix[chunk][bin], coalesced) and at
+// for every chunk the counts of the group's earlier chunks (prefix[chunk][bin], 16 bits each) and at
 // the end the group's totals (group_tot[group][bin]).  A chunk's write base for a bin is then
 //   bin_base[bin] + group_off[group][bin] + prefix[chunk][bin]
 // with group_off the exclusive scan of group_tot down the groups and bin_base the exclusive scan
@@ -115,7 +115,7 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t d, bool valid,
 template <int MODE>
 __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const uint64_t* packed, uint64_t R,
                                                             uint64_t chunk_rows, uint32_t G, int shift, int bits,
-                                                            RowFmt fmt, uint32_t n_terms, uint32_t* prefix,
+                                                            RowFmt fmt, uint32_t n_terms, unsigned short* prefix,
                                                             uint32_t* group_tot) {
     // one wavefront per chunk of the group, each with its own histogram: no barriers while counting
     __shared__ uint32_t hist[SORT_GROUP][SORT_MAX_BINS / 2];
@@ -196,17 +196,25 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
         }
     }
     __syncthreads();
-    // counts of the group's earlier chunks, per chunk and bin; group totals
-    for (uint32_t d = threadIdx.x; d < nb; d += HIST_THREADS) {
-        uint32_t run = 0;
+    // counts of the group's earlier chunks, per chunk and bin (two 16-bit entries per word: a group
+    // has at most SORT_GROUP * SORT_TILE = 65536 rows, so every count before its last chunk fits);
+    // group totals in 32 bits
+    static_assert(SORT_GROUP * SORT_TILE <= 65536, "prefix entries are 16 bits wide");
+    uint32_t* prefix32 = reinterpret_cast<uint32_t*>(prefix);
+    const uint32_t nw = max(nb / 2u, 1u);  // words per chunk
+    for (uint32_t x = threadIdx.x; x < nw; x += HIST_THREADS) {
+        uint32_t lo = 0, hi = 0;
 #pragma unroll 4
         for (uint32_t w = 0; w < SORT_GROUP; ++w) {
             if (g_begin + w < G) {
-                prefix[(size_t)(g_begin + w) * nb + d] = run;
-                run += (hist[w][d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+                prefix32[(size_t)(g_begin + w) * nw + x] = lo | (hi << 16);
+                const uint32_t word = hist[w][x];
+                lo += word & 0xFFFFu;
+                hi += word >> 16;
             }
         }
-        group_tot[(size_t)blockIdx.x * nb + d] = run;
+        group_tot[(size_t)blockIdx.x * nb + 2u * x] = lo;
+        if (2u * x + 1u < nb) group_tot[(size_t)blockIdx.x * nb + 2u * x + 1u] = hi;
     }
 }
 
@@ -250,7 +258,7 @@ constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-l
 template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                     uint64_t R, uint32_t G, int shift, int bits,
-                                                                    BuildCtx ctx, const uint32_t* prefix,
+                                                                    BuildCtx ctx, const unsigned short* prefix,
                                                                     const uint32_t* group_off, const uint32_t* bin_start) {
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
     __shared__ __align__(16) uint64_t rows_s[SORT_TILE];                       // the tile, locally ordered by digit
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
             // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
             // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
-            const uint32_t body = (!(ctx.debug & 1u) && valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
+            const uint32_t body = (valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
             const uint64_t first_key = lane_bcast<0>(ukey);
             const bool uniform = __all(ukey == first_key);
             uint32_t add = body;
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
 }
 
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
-                      int shift, int bits, const BuildCtx& ctx, uint32_t* prefix, uint32_t* group_tot, hipStream_t st) {
+                      int shift, int bits, const BuildCtx& ctx, unsigned short* prefix, uint32_t* group_tot, hipStream_t st) {
     dim3 grid((G + SORT_GROUP - 1) / SORT_GROUP), block(HIST_THREADS);
     if (mode == 0)
         hipLaunchKernelGGL(k_sort_hist<0>, grid, block, 0, st, raw, packed, R, chunk_rows, G, shift, bits, ctx.fmt, ctx.n_terms, prefix, group_tot);
@@ -507,7 +515,7 @@ void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint3
 }
 
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
-                         int bits, const BuildCtx& ctx, const uint32_t* prefix, const uint32_t* group_off,
+                         int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
                          const uint32_t* bin_start, hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
     if (mode == 0)

@@ -106,7 +106,6 @@ struct BuildCtx {
     RowFmt fmt;
     uint32_t n_terms, n_docs, n_articles;
     uint32_t check_order;   // rows declared unit-major: verify
-    uint32_t debug;         // experiment switches (SEBM25_DEBUG): 1 skip body lengths, 2 skip validation
     uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
     uint32_t* err;          // device error word
 };
@@ -115,11 +114,11 @@ struct BuildCtx {
 // sort_mode: 0 raw rows, digit taken from term_id alone; 1 raw rows, digit from the packed
 // key; 2 packed rows.
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
-                      int shift, int bits, const BuildCtx& ctx, uint32_t* prefix /* [G][bins] */,
+                      int shift, int bits, const BuildCtx& ctx, unsigned short* prefix /* [G][bins] */,
                       uint32_t* group_tot /* [groups][bins] */, hipStream_t st);
 void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot /* [bins] */, hipStream_t st);
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
-                         int bits, const BuildCtx& ctx, const uint32_t* prefix, const uint32_t* group_off,
+                         int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
                          const uint32_t* bin_start, hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
 size_t scan_tmp_words(size_t n);
