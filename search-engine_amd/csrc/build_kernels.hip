@@ -225,18 +225,27 @@ __global__ __launch_bounds__(256) void k_sort_group_scan(uint32_t* group_tot, ui
     const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (b >= nb) return;
     const uint32_t lane = lane_id();
+    constexpr int BATCH = 16;  // 64-group steps loaded together: one memory round trip per 1024 groups
     uint32_t carry = 0;
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += 64u) {
-        const uint32_t g = g0 + lane;
-        const uint32_t v = g < n_groups ? group_tot[(size_t)g * nb + b] : 0u;
-        uint32_t inc = v;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += 64u * BATCH) {
+        uint32_t v[BATCH];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t x = __shfl_up(inc, off);
-            if ((int)lane >= off) inc += x;
+        for (int k = 0; k < BATCH; ++k) {
+            const uint32_t g = g0 + (uint32_t)k * 64u + lane;
+            v[k] = g < n_groups ? group_tot[(size_t)g * nb + b] : 0u;
         }
-        if (g < n_groups) group_tot[(size_t)g * nb + b] = carry + inc - v;
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const uint32_t g = g0 + (uint32_t)k * 64u + lane;
+            uint32_t inc = v[k];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t x = __shfl_up(inc, off);
+                if ((int)lane >= off) inc += x;
+            }
+            if (g < n_groups) group_tot[(size_t)g * nb + b] = carry + inc - v[k];
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
     }
     if (lane == 0) bin_tot[b] = carry;
 }
