@@ -46,6 +46,7 @@ struct TopK {
     uint32_t n;
     uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
     uint32_t thr_tie;
+    double thr_score;  // thr_key as a score (-inf while fewer than k candidates are held): a cheap first test
 
     __device__ void init(unsigned char* lds) {
         key = reinterpret_cast<uint64_t*>(lds);
@@ -55,6 +56,7 @@ struct TopK {
         n = 0;
         thr_key = 0;
         thr_tie = 0xFFFFFFFFu;
+        thr_score = -__builtin_huge_val();
     }
     static constexpr size_t bytes() { return (size_t)CAP * 20; }
 
@@ -97,6 +99,7 @@ struct TopK {
         if (n == k && k > 0) {
             thr_key = key[k - 1];
             thr_tie = tie[k - 1];
+            thr_score = key_score(thr_key);
         }
     }
 
@@ -513,16 +516,23 @@ __global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
         for (uint32_t o0 = 0; o0 < n_used; o0 += 64) {
             const bool has = o0 + lane < n_used;
             double s = 0.0;
-            uint32_t m = 0, unit = 0, tie = 0;
+            uint32_t h = 0, unit = 0;
             if (has) {
-                const uint32_t h = used[o0 + lane];
+                h = used[o0 + lane];
                 s = acc[h];
-                m = cnt[h];
                 unit = tag[h];
                 tag[h] = HASH_EMPTY;
-                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
             }
-            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
+            // most units cannot enter the top k any more: test the score alone before anything else
+            const bool may = has && s >= tk.thr_score;
+            if (__ballot(may)) {
+                uint32_t m = 0, tie = 0;
+                if (may) {
+                    m = cnt[h];
+                    tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+                }
+                tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
