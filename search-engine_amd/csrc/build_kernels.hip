@@ -673,8 +673,10 @@ __device__ __forceinline__ bool tf_big(const RowBits& b, uint64_t r) {
 // weight of one row in tenths, tf < 2^24: web tf * {32, 17, 10}[field code] (W = 3.2 / 1.7 / 1.0,
 // search_service.py:19-27), news 10 * tf (:84-87)
 __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool news) {
-    const uint32_t fc = shr_lo32(r, b.fc_sh) & 3u;
-    const uint32_t mult = news ? 10u : (fc == 1u ? 32u : fc == 2u ? 17u : 10u);
+    // the multiplier by table: byte fc of 0x0A11200A (10, 32, 17, 10), selected with the field code
+    // taken from the row already multiplied by 8 (fc_sh >= 8 because tf has at least 8 bits)
+    const uint32_t sh = shr_lo32(r, b.fc_sh - 3) & 0x18u;
+    const uint32_t mult = news ? 10u : __builtin_amdgcn_ubfe(0x0A11200Au, sh, 8u);
     return __umul24(lo32(r) & b.tf24_mask, mult);
 }
 
@@ -760,21 +762,24 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
         // ---- phase 1: the word of every row of the batch, and of the first round behind it
         uint32_t v[RED_ROUNDS + 1];
         bool news[RED_ROUNDS];
-        uint64_t big = 0;
+        uint32_t big = 0;  // per lane: tf bits from 2^24 up seen in this batch (rows of this range only)
         uint64_t before = carry;
+        if (b0 + 2u * RED_BATCH > R) {  // only a range's last batches reach behind the last row
+#pragma unroll
+            for (int j = 0; j < RED_ROUNDS; ++j)
+                if (b0 + (uint32_t)j * 64u + lane >= R) ra[j] = behind;
+            if (b0 + RED_BATCH + lane >= R) rb1[0] = behind;
+        }
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
-            if (b0 + (uint32_t)j * 64u + lane >= R) ra[j] = behind;
             news[j] = is_news(rb, ra[j]);
             v[j] = round_word(ra[j], before, news[j]);
-            big |= __ballot(tf_big(rb, ra[j]) && b0 + (uint32_t)j * 64u + lane < end);
+            const uint32_t bits = (hi32(ra[j]) & rb.big_hi) | (lo32(ra[j]) & rb.big_lo);
+            big |= b0 + (uint32_t)j * 64u + lane < end ? bits : 0u;
             before = lane_bcast<63>(ra[j]);
         }
-        {
-            const uint64_t x = (b0 + RED_BATCH + lane >= R) ? behind : rb1[0];
-            v[RED_ROUNDS] = round_word(x, before, is_news(rb, x));
-        }
-        if (big && lane == 0) atomicOr(err, DEV_NEED_FIXUP);  // a tf of 2^24 or more: exact weights later
+        v[RED_ROUNDS] = round_word(rb1[0], before, is_news(rb, rb1[0]));
+        if (__ballot(big != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);  // a tf of 2^24 or more: exact weights later
 
         // ---- phase 2: slots, term boundaries, df
 #pragma unroll
