@@ -710,8 +710,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
     const RowBits rb(fmt);
     const uint32_t lane = lane_id();
     const uint64_t lt = lanemask_lt();
-    const uint32_t begin = c * chunk_rows;  // host guarantees n_chunks * chunk_rows + 3 * RED_BATCH < 2^32
-    const uint32_t end = min(R, begin + chunk_rows);
+    const uint32_t begin = c * chunk_rows;  // < R; the host keeps R + 3 * RED_BATCH below 2^32
+    const uint32_t end = R - begin < chunk_rows ? R : begin + chunk_rows;
     const uint64_t key_lsb = 1ull << fmt.key_shift();
     // rows behind the last one read as a row of another key; so does the row before row 0
     const uint64_t behind = rows[R - 1] ^ key_lsb;
