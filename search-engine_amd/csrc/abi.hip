@@ -268,6 +268,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 2));
         HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
         HIP_TRY(ix, ix->bin_start.ensure((size_t)SORT_MAX_BINS * 4));
+        HIP_TRY(ix, ix->scan_tmp.ensure(sort_offsets_tmp_words() * 4));
 
         BuildCtx ctx{};
         ctx.fmt = fmt;
@@ -294,10 +295,10 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
             launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, ix->stream);
             phase_end(ix);
             phase_begin(ix, scan_names[p]);
-            launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->stream);
+            launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->scan_tmp.as<uint32_t>(), ix->stream);
             phase_end(ix);
             phase_begin(ix, scat_names[p]);
-            launch_sort_scatter(mode, raw, src_packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start, ix->stream);
+            launch_sort_scatter(mode, raw, src_packed, dst, R, G, shift, bits, ctx, prefix, group_off, ix->stream);
             phase_end(ix);
             src_packed = dst;
             shift += bits;

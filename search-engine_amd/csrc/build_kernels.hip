@@ -66,9 +66,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // workgroup counts the digits of the chunks of one group, one wavefront per chunk, and writes
 // for every chunk the counts of the group's earlier chunks (prefix[chunk][bin], 16 bits each) and at
 // the end the group's totals (group_tot[group][bin]).  A chunk's write base for a bin is then
-//   bin_base[bin] + group_off[group][bin] + prefix[chunk][bin]
-// with group_off the exclusive scan of group_tot down the groups and bin_base the exclusive scan
-// of the bin totals.  Chunks are small, so that the workgroups of one XCD, which take consecutive
+//   group_off[group][bin] + prefix[chunk][bin]
+// with group_off = first slot of the bin (exclusive scan of the bin totals) + the exclusive scan of
+// group_tot down the groups.  Chunks are small, so that the workgroups of one XCD, which take consecutive
 // chunks, append to each bin next to one another and their runs merge into full lines in L2.
 // MODE 0: raw rows, only term_id is read (the digit lies inside the term bits)
 // MODE 1: raw rows, digit taken from the key packed from term / source / unit
@@ -218,36 +218,61 @@ __global__ __launch_bounds__(HIST_THREADS) void k_sort_hist(RawRows raw, const u
     }
 }
 
-// group_tot[group][bin] -> exclusive scan down the groups, in place; bin_tot[bin] = column total.
-// One wavefront per bin.
-__global__ __launch_bounds__(256) void k_sort_group_scan(uint32_t* group_tot, uint32_t n_groups, uint32_t nb,
-                                                         uint32_t* bin_tot) {
-    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+// group_tot[group][bin] -> first slot of every (group, bin): an exclusive scan down the groups plus
+// the first slot of the bin.  The groups are cut into SCAN_SEGS segments; lane = bin, so every access
+// is a coalesced 256-byte piece of a row of the matrix.
+//   k_sort_seg_sums : seg_tot[seg][bin] = sum of the segment's groups
+//   k_sort_seg_scan : seg_tot -> exclusive scan down the segments (in place), bin_tot[bin] = total
+//   (exclusive scan of bin_tot -> first slot of every bin)
+//   k_sort_seg_apply: group_tot[group][bin] -> bin start + segment start + groups before it
+constexpr uint32_t SCAN_SEGS = 64;
+
+__global__ __launch_bounds__(256) void k_sort_seg_sums(const uint32_t* group_tot, uint32_t n_groups, uint32_t nb,
+                                                       uint32_t seg_len, uint32_t* seg_tot) {
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);  // (bin block, segment)
+    const uint32_t blocks = (nb + 63u) / 64u;
+    const uint32_t seg = w / blocks, b = (w % blocks) * 64u + lane_id();
+    if (seg >= SCAN_SEGS || b >= nb) return;
+    const uint32_t g0 = seg * seg_len, g1 = min(n_groups, g0 + seg_len);
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t g = g0; g < g1; ++g) sum += group_tot[(size_t)g * nb + b];
+    seg_tot[seg * nb + b] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_sort_seg_scan(uint32_t* seg_tot, uint32_t nb, uint32_t* bin_tot) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= nb) return;
-    const uint32_t lane = lane_id();
-    constexpr int BATCH = 16;  // 64-group steps loaded together: one memory round trip per 1024 groups
-    uint32_t carry = 0;
-    for (uint32_t g0 = 0; g0 < n_groups; g0 += 64u * BATCH) {
+    uint32_t run = 0;
+#pragma unroll 8
+    for (uint32_t s = 0; s < SCAN_SEGS; ++s) {
+        const uint32_t v = seg_tot[s * nb + b];
+        seg_tot[s * nb + b] = run;
+        run += v;
+    }
+    bin_tot[b] = run;
+}
+
+__global__ __launch_bounds__(256) void k_sort_seg_apply(uint32_t* group_tot, uint32_t n_groups, uint32_t nb,
+                                                        uint32_t seg_len, const uint32_t* seg_off,
+                                                        const uint32_t* bin_start) {
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t blocks = (nb + 63u) / 64u;
+    const uint32_t seg = w / blocks, b = (w % blocks) * 64u + lane_id();
+    if (seg >= SCAN_SEGS || b >= nb) return;
+    const uint32_t g0 = seg * seg_len, g1 = min(n_groups, g0 + seg_len);
+    uint32_t run = bin_start[b] + seg_off[seg * nb + b];
+    constexpr uint32_t BATCH = 8;  // loads of a batch are independent: issued together
+    for (uint32_t g = g0; g < g1; g += BATCH) {
         uint32_t v[BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const uint32_t g = g0 + (uint32_t)k * 64u + lane;
-            v[k] = g < n_groups ? group_tot[(size_t)g * nb + b] : 0u;
-        }
+        for (uint32_t k = 0; k < BATCH; ++k) v[k] = g + k < g1 ? group_tot[(size_t)(g + k) * nb + b] : 0u;
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const uint32_t g = g0 + (uint32_t)k * 64u + lane;
-            uint32_t inc = v[k];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t x = __shfl_up(inc, off);
-                if ((int)lane >= off) inc += x;
-            }
-            if (g < n_groups) group_tot[(size_t)g * nb + b] = carry + inc - v[k];
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        for (uint32_t k = 0; k < BATCH; ++k) {
+            if (g + k < g1) group_tot[(size_t)(g + k) * nb + b] = run;
+            run += v[k];
         }
     }
-    if (lane == 0) bin_tot[b] = carry;
 }
 
 constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-length counters
@@ -268,7 +293,7 @@ template <int MODE>
 __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                     uint64_t R, uint32_t G, int shift, int bits,
                                                                     BuildCtx ctx, const unsigned short* prefix,
-                                                                    const uint32_t* group_off, const uint32_t* bin_start) {
+                                                                    const uint32_t* group_off) {
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
     __shared__ __align__(16) uint64_t rows_s[SORT_TILE];                       // the tile, locally ordered by digit
     __shared__ uint32_t base[SORT_MAX_BINS];  // first the chunk's write base per digit, then global minus local slot
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         first_m = raw.meta[tile0];
     }
     for (uint32_t d = t; d < nb; d += SORT_THREADS)
-        base[d] = bin_start[d] + group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
+        base[d] = group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
     for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
     for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS) + DL_SPAN; x += SORT_THREADS) mtab[x] = 0;
     __syncthreads();
@@ -516,23 +541,32 @@ void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R,
 
 __global__ void k_scan_single(uint32_t* sums, size_t n);
 
-// group_tot -> group offsets (in place); bin_tot -> first slot of every bin (in place)
-void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot, hipStream_t st) {
+size_t sort_offsets_tmp_words() { return (size_t)SCAN_SEGS * SORT_MAX_BINS; }
+
+// group_tot -> first slot of every (group, bin), in place; bin_tot [bins] and seg_tmp
+// [sort_offsets_tmp_words()] are scratch
+void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot, uint32_t* seg_tmp,
+                         hipStream_t st) {
     const uint32_t nb = 1u << bits;
-    hipLaunchKernelGGL(k_sort_group_scan, dim3((nb + 3u) / 4u), dim3(256), 0, st, group_tot, n_groups, nb, bin_tot);
+    const uint32_t seg_len = (n_groups + SCAN_SEGS - 1u) / SCAN_SEGS;
+    const uint32_t waves = ((nb + 63u) / 64u) * SCAN_SEGS;
+    hipLaunchKernelGGL(k_sort_seg_sums, dim3((waves + 3u) / 4u), dim3(256), 0, st, group_tot, n_groups, nb, seg_len, seg_tmp);
+    hipLaunchKernelGGL(k_sort_seg_scan, dim3((nb + 255u) / 256u), dim3(256), 0, st, seg_tmp, nb, bin_tot);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bin_tot, (size_t)nb);
+    hipLaunchKernelGGL(k_sort_seg_apply, dim3((waves + 3u) / 4u), dim3(256), 0, st, group_tot, n_groups, nb, seg_len,
+                       seg_tmp, bin_tot);
 }
 
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
                          int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
-                         const uint32_t* bin_start, hipStream_t st) {
+                         hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_scatter_tile<0>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<0>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_scatter_tile<1>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<1>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
     else
-        hipLaunchKernelGGL(k_sort_scatter_tile<2>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, bin_start);
+        hipLaunchKernelGGL(k_sort_scatter_tile<2>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------

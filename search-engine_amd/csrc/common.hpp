@@ -116,10 +116,12 @@ struct BuildCtx {
 void launch_sort_hist(int mode, RawRows raw, const uint64_t* packed, uint64_t R, uint64_t chunk_rows, uint32_t G,
                       int shift, int bits, const BuildCtx& ctx, unsigned short* prefix /* [G][bins] */,
                       uint32_t* group_tot /* [groups][bins] */, hipStream_t st);
-void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot /* [bins] */, hipStream_t st);
+size_t sort_offsets_tmp_words();
+void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint32_t* bin_tot /* [bins] */,
+                         uint32_t* seg_tmp /* [sort_offsets_tmp_words()] */, hipStream_t st);
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
                          int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
-                         const uint32_t* bin_start, hipStream_t st);
+                         hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);

@@ -10,6 +10,7 @@ with plain torch tensor operations on the same rows (no library code on the chec
     on the full (term, source, unit) key, give the same statistics and bit-identical results.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -18,7 +19,7 @@ import search_engine_amd as se
 
 pytestmark = pytest.mark.gpu
 
-DOCS, VOCAB = 1_000_000, 500_000
+DOCS, VOCAB = int(os.environ.get("SEBM25_TEST_DOCS", 1_000_000)), 500_000   # the env override is for one-off runs at larger sizes
 
 
 @pytest.fixture(scope="module")
