@@ -4,7 +4,7 @@
 One "step" = one full statistics job over this rank's shard of the synthetic Zipfian corpus,
 rows already resident in HBM: radix sort -> segmented reduction into the CSR index -> df /
 document totals -> (N > 1: all-reduce of df[V] and the document totals over RCCL) -> idf.
-Workload at N = 1: BASELINE config 2 (1M docs, 500k-term vocabulary, ~300 draws per doc);
+Workload at N = 1: benchmark configuration 2 (1M docs, 500k-term vocabulary, ~300 draws per doc);
 at N > 1 every rank builds its own 1M-doc shard (weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--docs D] [--queries Q] ...
@@ -194,7 +194,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"BM25 index build, {args.docs} docs per GPU, vocab {args.vocab}, Zipf s=1, "
-                               f"~300 body draws/doc (BASELINE config 2 per GPU)",
+                               f"~300 body draws/doc (benchmark configuration 2 per GPU)",
                    "rows_per_gpu": int(info.n_rows), "postings_per_gpu": int(info.n_postings),
                    "sort_passes": int(info.sort_passes), "parallelism": f"doc-sharded x{world}"},
         "roofline": roofline,

@@ -23,7 +23,7 @@ def test_build_matches_oracle(gpu_index_factory, n_docs, n_terms, n_articles):
 
 
 def test_build_10k_docs_two_passes(gpu_index_factory):
-    # BASELINE config 1 size: 10k docs, 500k-term vocabulary -> 19 term bits, two radix passes
+    # benchmark configuration 1 size: 10k docs, 500k-term vocabulary -> 19 term bits, two radix passes
     c = small_corpus(n_docs=10_000, n_terms=500_000, n_articles=500)
     orc = oracle_index(c)
     ix = gpu_index_factory()
