@@ -689,18 +689,26 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
             plan.push_back({it, q_len[q] / ns});
         }
     }
-    // fast-path items (few lists) first, each group longest first so the tail of the launch is short work
+    // fast-path items (few lists) first, each group longest first so the tail of the launch is short
+    // work; a counting sort on the length's bit count and its next four bits (order within 6 %),
+    // linear in the item count
     const uint32_t fast_t = score_fast_max_terms();
-    std::stable_sort(plan.begin(), plan.end(), [fast_t](const Planned& a, const Planned& b) {
-        const bool fa = a.it.n_terms <= fast_t, fb = b.it.n_terms <= fast_t;
-        if (fa != fb) return fa;
-        return a.len > b.len;
-    });
     std::vector<QItem> items(plan.size());
     uint32_t n_fast = 0;
-    for (size_t i = 0; i < plan.size(); ++i) {
-        items[i] = plan[i].it;
-        n_fast += plan[i].it.n_terms <= fast_t;
+    {
+        constexpr uint32_t SUB = 16, PER_GROUP = 65 * SUB;
+        auto bucket_of = [fast_t](const Planned& p) -> uint32_t {
+            uint32_t bits = 0;
+            for (uint64_t l = p.len; l; l >>= 1) ++bits;  // 0..64
+            const uint32_t frac = bits > 4 ? (uint32_t)(p.len >> (bits - 5)) & (SUB - 1) : (uint32_t)p.len & (SUB - 1);
+            const uint32_t key = bits * SUB + frac;        // grows with the length
+            return (p.it.n_terms <= fast_t ? 0u : PER_GROUP) + (PER_GROUP - 1u - key);
+        };
+        std::vector<uint32_t> start(2 * PER_GROUP + 1, 0);
+        for (const Planned& p : plan) ++start[bucket_of(p) + 1];
+        for (size_t b = 0; b + 1 < start.size(); ++b) start[b + 1] += start[b];
+        n_fast = start[PER_GROUP];
+        for (const Planned& p : plan) items[start[bucket_of(p)]++] = p.it;
     }
 
     // ---- device buffers
