@@ -87,11 +87,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # SEBM25_BENCH_REHEARSAL=1: every rank on GPU 0 and collectives over gloo, to rehearse the
+    # multi-rank code path on a one-GPU box (the numbers of such a run mean nothing)
+    rehearsal = os.environ.get("SEBM25_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ix = se.Index(local_rank)
     ix.set_stream(torch.cuda.current_stream().cuda_stream)
