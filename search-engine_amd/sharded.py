@@ -36,8 +36,8 @@ class ShardedIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._buf = None   # int32[V + 16]: df, then the four totals as 16-bit limbs (one all-reduce for both)
         self._df = None
-        self._tot = torch.zeros(4, dtype=torch.int64, device=self.device)
 
     # ---- statistics job
     def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
@@ -48,15 +48,19 @@ class ShardedIndex:
         e.build_local(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags,
                       unit_major=unit_major)
         e.set_unit_base(doc_base, article_base)
-        if self._df is None or self._df.numel() != n_terms:
-            self._df = torch.zeros(n_terms, dtype=torch.int32, device=self.device)
+        if self._buf is None or self._buf.numel() != n_terms + 16:
+            self._buf = torch.zeros(n_terms + 16, dtype=torch.int32, device=self.device)
+            self._df = self._buf[:n_terms]
         _, t = e.local_stats(self._df)
         if self.world > 1:
-            self._tot.copy_(torch.tensor([t.n_done, t.n_wc, t.sum_wc, t.n_postings], dtype=torch.int64))
-            dist.all_reduce(self._df, group=self.group)    # df[V]: SUM over shards
-            dist.all_reduce(self._tot, group=self.group)   # N, AVG numerator and denominator, posting count
-            g = self._tot.tolist()
-            t = DocTotals(*g)
+            # 64-bit totals travel as four 16-bit limbs each, so that an int32 SUM over the ranks cannot
+            # overflow (up to 32768 ranks) and df and totals share one collective
+            vals = (t.n_done, t.n_wc, t.sum_wc, t.n_postings)
+            limbs = [(int(v) >> (16 * j)) & 0xFFFF for v in vals for j in range(4)]
+            self._buf[n_terms:].copy_(torch.tensor(limbs, dtype=torch.int32))
+            dist.all_reduce(self._buf, group=self.group)    # SUM over shards (RCCL over xGMI with backend nccl)
+            got = self._buf[n_terms:].tolist()
+            t = DocTotals(*(sum(int(got[4 * i + j]) << (16 * j) for j in range(4)) for i in range(4)))
         e.finalize(self._df, t)
         self.totals = t
         return t
