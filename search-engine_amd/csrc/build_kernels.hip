@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // MODE 1: raw rows, digit taken from the key packed from term / source / unit
 // MODE 2: packed rows
 constexpr int HIST_THREADS = 1024;
-constexpr int HIST_UNROLL = 4;
+constexpr int HIST_UNROLL = 8;
 
 // One count per lane.  Skewed or sorted input gives many lanes of a wave the same digit, and 64
 // lanes adding to one LDS word serialise.  So the lanes that hold `hot` (the digit with the
