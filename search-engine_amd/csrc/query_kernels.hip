@@ -36,7 +36,7 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, ui
 }
 
 // Candidate buffer of one wave (LDS).  Slots [0, n) are live; after cut() they are sorted best
-// first and n <= k.
+// first and n <= k.  offer() adds up to 64 candidates behind a cut, so CAP must be at least k + 64.
 template <int CAP>
 struct TopK {
     uint64_t* key;
