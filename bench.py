@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--terms-per-query", type=int, default=3)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--k2", type=int, default=220, help="second scoring run at this k (0 = skip)")
     ap.add_argument("--query-steps", type=int, default=5)
     ap.add_argument("--cpu-docs", type=int, default=1_000_000, help="docs in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -246,6 +247,25 @@ def main():
                          "traffic": None, "kernel": "k_score", "kernel_ms": score_ms, "alg_bytes": alg_q,
                          "phases_ms": {n: round(ms, 4) for n, ms in qphases}},
         }
+
+    # ---- the same batch at the reference's own candidate limit (limit=20 -> k=220, search_service.py:236-239)
+    if not args.no_query and args.k2 > 0:
+        res2 = {k: torch.empty((args.queries, args.k2), dtype=dt, device=dev) for k, dt in
+                (("unit", torch.int32), ("score", torch.float64), ("matched", torch.int32), ("tie", torch.int32))}
+        res2["count"] = torch.empty(args.queries, dtype=torch.int32, device=dev)
+        ix.search(qs, args.k2, out=res2)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.query_steps):
+            ix.search(qs, args.k2, out=res2)
+        sync()
+        tq2 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([tq2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tq2 = float(tmax.item())
+        out["query"]["candidate_limit_run"] = {"k": args.k2, "value": args.queries * args.query_steps / tq2,
+                                               "unit": "queries/s", "ms_per_batch": tq2 / args.query_steps * 1e3}
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # rows of the first cpu_docs documents: a prefix of the unit-major corpus
