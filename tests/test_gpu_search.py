@@ -20,7 +20,7 @@ def built(gpu_index_factory):
     orc = oracle_index(c)
     ix = gpu_index_factory()
     gpu_build(ix, c)
-    ix.set_idf(orc.idf)  # same idf bits on both sides: scores from the float postings are then bit-exact
+    ix.set_idf(orc.idf)  # same idf bits on both sides: scores from the integer postings are then bit-exact
     return c, orc, ix
 
 
