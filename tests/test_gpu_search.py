@@ -156,3 +156,18 @@ def test_sharded_build_and_merge_equals_unsharded(gpu_index_factory):
             np.testing.assert_array_equal(merged["unit"][qi, :n], ru)
             np.testing.assert_array_equal(merged["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
             np.testing.assert_array_equal(merged["matched"][qi, :n], rm)
+
+@pytest.mark.parametrize("tpq", [5, 6, 8, 9])
+def test_queries_with_five_to_nine_terms(built, tpq):
+    """More lists than the fast path takes (4): the general kernel, same results."""
+    c, orc, ix = built
+    qs = _queries(c["n_terms"], 30, tpq, min_rank=1, seed=77 + tpq)
+    for k in (10, 100):
+        out = ix.search(qs, k)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, level="csr")
+            n = int(out["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
