@@ -37,12 +37,14 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, ui
 
 // Candidate buffer of one wave (LDS).  Slots [0, n) are live; after cut() they are sorted best
 // first and n <= k.  offer() adds up to 64 candidates behind a cut, so CAP must be at least k + 64.
-template <int CAP>
+// HAS_TIE = false: the tie-break key of every candidate equals its unit (no url ranks were given), so
+// it is not stored.
+template <int CAP, bool HAS_TIE = true>
 struct TopK {
     uint64_t* key;
-    uint32_t* tie;
     uint32_t* unit;
-    uint32_t* mat;
+    uint32_t* tie_;          // only when HAS_TIE
+    unsigned char* mat;      // matched terms (at most 64)
     uint32_t n;
     uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
     uint32_t thr_tie;
@@ -50,22 +52,23 @@ struct TopK {
 
     __device__ void init(unsigned char* lds) {
         key = reinterpret_cast<uint64_t*>(lds);
-        tie = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
-        unit = tie + CAP;
-        mat = unit + CAP;
+        unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
+        tie_ = unit + CAP;
+        mat = reinterpret_cast<unsigned char*>(unit + (HAS_TIE ? 2 : 1) * CAP);
         n = 0;
         thr_key = 0;
         thr_tie = 0xFFFFFFFFu;
         thr_score = -__builtin_huge_val();
     }
-    static constexpr size_t bytes() { return (size_t)CAP * 20; }
+    static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + (HAS_TIE ? 4 : 0) + 1) + 15) / 16 * 16; }
+    __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
 
     // wave-wide bitonic sort of all CAP slots (dead slots hold the worst key), best first
     __device__ void cut(uint32_t k) {
         const uint32_t lane = lane_id();
         for (uint32_t i = n + lane; i < CAP; i += 64) {
             key[i] = 0;
-            tie[i] = 0xFFFFFFFFu;
+            if (HAS_TIE) tie_[i] = 0xFFFFFFFFu;
             unit[i] = 0xFFFFFFFFu;
             mat[i] = 0;
         }
@@ -77,17 +80,19 @@ struct TopK {
                     const uint32_t hi = lo | stride;
                     const bool desc = (lo & size) == 0;  // block direction
                     const uint64_t klo = key[lo], khi = key[hi];
-                    const uint32_t tlo = tie[lo], thi = tie[hi];
+                    const uint32_t ul = unit[lo], uh = unit[hi];
+                    const uint32_t tlo = HAS_TIE ? tie_[lo] : ul, thi = HAS_TIE ? tie_[hi] : uh;
                     const bool hi_first = better(khi, thi, klo, tlo);
                     if (hi_first == desc) {
                         key[lo] = khi;
                         key[hi] = klo;
-                        tie[lo] = thi;
-                        tie[hi] = tlo;
-                        const uint32_t ul = unit[lo], uh = unit[hi];
+                        if (HAS_TIE) {
+                            tie_[lo] = thi;
+                            tie_[hi] = tlo;
+                        }
                         unit[lo] = uh;
                         unit[hi] = ul;
-                        const uint32_t ml = mat[lo], mh = mat[hi];
+                        const unsigned char ml = mat[lo], mh = mat[hi];
                         mat[lo] = mh;
                         mat[hi] = ml;
                     }
@@ -98,7 +103,7 @@ struct TopK {
         if (n > k) n = k;
         if (n == k && k > 0) {
             thr_key = key[k - 1];
-            thr_tie = tie[k - 1];
+            thr_tie = tie(k - 1);
             thr_score = key_score(thr_key);
         }
     }
@@ -116,9 +121,9 @@ struct TopK {
         if (pass) {
             const uint32_t pos = n + (uint32_t)__popcll(pm & lanemask_lt());
             key[pos] = ck;
-            tie[pos] = ct;
+            if (HAS_TIE) tie_[pos] = ct;
             unit[pos] = cu;
-            mat[pos] = cm;
+            mat[pos] = (unsigned char)cm;
         }
         n += (uint32_t)__popcll(pm);
         __builtin_amdgcn_wave_barrier();
@@ -132,7 +137,7 @@ struct TopK {
             o_unit[i] = live ? unit[i] : 0xFFFFFFFFu;
             o_score[i] = live ? key_score(key[i]) : 0.0;
             o_mat[i] = live ? mat[i] : 0u;
-            if (o_tie) o_tie[i] = live ? tie[i] : 0xFFFFFFFFu;
+            if (o_tie) o_tie[i] = live ? tie(i) : 0xFFFFFFFFu;
         }
         if (lane_id() == 0) *o_count = n;
     }
@@ -400,13 +405,14 @@ __global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
 constexpr int HASH_SLOTS = 512;
 constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
 
-template <int CAP>
+// HAS_RANK: url ranks were given (a.url_rank != null); without them a unit's tie-break key is its id
+template <int CAP, bool HAS_RANK>
 __global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
     __shared__ __align__(16) double acc[HASH_SLOTS];
     __shared__ uint32_t tag[HASH_SLOTS];
     __shared__ unsigned char cnt[HASH_SLOTS];
     __shared__ unsigned short used[FAST_T * 64];
-    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP, HAS_RANK>::bytes()];
 
     const QItem it = a.items[blockIdx.x];
     const uint32_t lane = lane_id();
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
         load_chunk(t, pos[t] + 128u, cur, u2[t], w2[t]);
     }
     for (uint32_t x = lane; x < HASH_SLOTS; x += 64) tag[x] = HASH_EMPTY;
-    TopK<CAP> tk;
+    TopK<CAP, HAS_RANK> tk;
     tk.init(topk_mem);
     __builtin_amdgcn_wave_barrier();
 
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
                 uint32_t m = 0, tie = 0;
                 if (may) {
                     m = cnt[h];
-                    tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+                    tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
                 }
                 tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
             }
@@ -577,9 +583,15 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st) {
     if (n_fast && window == 0) {  // posting-space steps with hashed accumulators
         dim3 grid(n_fast), block(64);
-        if (a.k <= 64) hipLaunchKernelGGL(k_score_hash<128>, grid, block, 0, st, a);
-        else if (a.k <= 256) hipLaunchKernelGGL(k_score_hash<512>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_score_hash<4096>, grid, block, 0, st, a);
+        if (a.url_rank) {
+            if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, true>), grid, block, 0, st, a);
+            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<512, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_hash<4096, true>), grid, block, 0, st, a);
+        } else {
+            if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, false>), grid, block, 0, st, a);
+            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<512, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_hash<4096, false>), grid, block, 0, st, a);
+        }
     } else if (n_fast) {
         dim3 grid(n_fast), block(64);
         if (a.k <= 64) {
