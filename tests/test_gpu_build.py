@@ -189,3 +189,30 @@ def test_row_counts_around_tile_chunk_and_group_edges(gpu_index_factory, n_terms
         gpu_build(ix, c, word_count=None)
         assert_build_matches(ix, orc)
         orc.close()
+
+
+def test_mid_size_with_news_and_unfinished_docs(gpu_index_factory):
+    """50k docs + 5k news articles, a fifth of the docs not 'done', some word counts NULL: the largest
+    case the CPU oracle still answers in seconds; build and both kinds of search bit for bit."""
+    from oracle import oracle as O
+
+    c = small_corpus(n_docs=50_000, n_terms=100_000, n_articles=5_000)
+    rng = np.random.default_rng(5)
+    flags = np.where(rng.random(50_000) < 0.8, se.DOC_DONE, 0).astype(np.uint8)
+    flags |= np.where(rng.random(50_000) < 0.05, se.DOC_WC_NULL, 0).astype(np.uint8)
+    orc = oracle_index(c, doc_flags=flags)
+    ix = gpu_index_factory()
+    gpu_build(ix, c, doc_flags=flags)
+    assert_build_matches(ix, orc)
+    ix.set_idf(orc.idf)  # same idf bits on both sides
+    qs = O.gen_queries(99, c["n_terms"], O.zipf_cdf(c["n_terms"]), 1, 60, 3)
+    for source in (se.SRC_WEB, se.SRC_NEWS):
+        out = ix.search(qs, 25, source=source)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, 25, source=source, level="csr")
+            n = int(out["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+    orc.close()
