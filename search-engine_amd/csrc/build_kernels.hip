@@ -296,11 +296,12 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
                                                                     const uint32_t* group_off) {
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
     __shared__ __align__(16) uint64_t rows_s[SORT_TILE];                       // the tile, locally ordered by digit
-    __shared__ uint32_t base[SORT_MAX_BINS];  // first the chunk's write base per digit, then global minus local slot
+    __shared__ __align__(8) uint32_t base[SORT_MAX_BINS];  // first the chunk's write base per digit, then global minus local slot
     __shared__ uint32_t wave_tot[SORT_WAVES];
     uint32_t* mtab = reinterpret_cast<uint32_t*>(rows_s);     // per wave: lane masks per folded digit (16 KB)
     uint32_t* dl_s = mtab + SORT_WAVES * (2u << MATCH_TAB_BITS);  // body length per doc of this tile (2 KB)
     static_assert(SORT_WAVES * (2u << MATCH_TAB_BITS) * 4 + DL_SPAN * 4 <= SORT_TILE * 8, "aliases fit the tile buffer");
+    uint32_t* wh32 = reinterpret_cast<uint32_t*>(&whist[0][0]);  // two 16-bit counters per word
 
     const RowFmt fmt = ctx.fmt;
     const uint32_t nb = 1u << bits, mask = nb - 1u;
@@ -314,21 +315,37 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     const uint64_t tile0 = (uint64_t)chunk * SORT_TILE;
     const uint64_t end = min(R, tile0 + SORT_TILE);
     const uint64_t wave0 = tile0 + (uint64_t)wave * 64u * SORT_ITEMS;  // wave w owns 8 rounds of 64 rows
-    uint32_t* wh32 = reinterpret_cast<uint32_t*>(&whist[0][0]);  // two 16-bit counters per word
 
+    // the chunk's write base of digits 2t and 2t + 1: one 8-byte and one 4-byte load per thread from
+    // clamped addresses, no loop (loads retire in issue order, a loop would wait for the rows too)
+    static_assert(SORT_MAX_BINS == 2 * SORT_THREADS, "two digits per thread");
+    uint2 base_g = make_uint2(0u, 0u);
+    uint32_t base_p = 0;
+    auto load_bases = [&]() {
+        const uint32_t d = min(2u * t, nb - 2u);
+        base_g = *reinterpret_cast<const uint2*>(group_off + (size_t)(chunk / SORT_GROUP) * nb + d);
+        base_p = *reinterpret_cast<const uint32_t*>(prefix + (size_t)chunk * nb + d);
+    };
+    const uint32_t n_tile = (uint32_t)(end - tile0);
+    const uint32_t l0 = wave * 64u * SORT_ITEMS + lane;  // position in the tile of this lane's row of round 0
+    const uint64_t* packed_t = packed + tile0;
+    const uint32_t* term_t = raw.term + tile0;
+    const uint32_t* unit_t = raw.unit + tile0;
+    const uint32_t* tf_t = raw.tf + tile0;
+    const uint8_t* meta_t = raw.meta + tile0;
     uint64_t row[SORT_ITEMS];
     uint32_t term[SORT_ITEMS], unit[SORT_ITEMS], tfv[SORT_ITEMS], m[SORT_ITEMS];  // raw columns (MODE 0, 1)
     uint32_t prev_u = 0, prev_m = 0, first_u = 0, first_m = 0;  // row before this wave's rows; first row of the tile
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
-        const uint64_t i = min(wave0 + (uint64_t)j * 64u + lane, end - 1);
+        const uint32_t i = min(l0 + (uint32_t)j * 64u, n_tile - 1u);  // 32-bit offsets from the tile's uniform base
         if (MODE == 2) {
-            row[j] = packed[i];
+            row[j] = packed_t[i];
         } else {
-            term[j] = raw.term[i];
-            unit[j] = raw.unit[i];
-            tfv[j] = raw.tf[i];
-            m[j] = raw.meta[i];
+            term[j] = term_t[i];
+            unit[j] = unit_t[i];
+            tfv[j] = tf_t[i];
+            m[j] = meta_t[i];
         }
     }
     if (MODE != 2) {
@@ -338,8 +355,12 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         first_u = raw.unit[tile0];
         first_m = raw.meta[tile0];
     }
-    for (uint32_t d = t; d < nb; d += SORT_THREADS)
-        base[d] = group_off[(size_t)(chunk / SORT_GROUP) * nb + d] + prefix[(size_t)chunk * nb + d];
+    asm volatile("" ::: "memory");  // keeps the loads below from moving up between the row loads
+    load_bases();
+    // every load above is issued before anything waits for the bases (the operands tie the adds below to this point)
+    asm volatile("" : "+v"(base_g.x), "+v"(base_g.y), "+v"(base_p)::"memory");
+    // entries of digits >= nb hold a clamped copy and are never read
+    *reinterpret_cast<uint2*>(&base[2u * t]) = make_uint2(base_g.x + (base_p & 0xFFFFu), base_g.y + (base_p >> 16));
     for (uint32_t x = t; x < SORT_WAVES * SORT_MAX_BINS / 2; x += SORT_THREADS) wh32[x] = 0;
     for (uint32_t x = t; x < SORT_WAVES * (2u << MATCH_TAB_BITS) + DL_SPAN; x += SORT_THREADS) mtab[x] = 0;
     __syncthreads();
@@ -349,24 +370,30 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     if (MODE == 2) {
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j)
-            if (wave0 + (uint64_t)j * 64u + lane >= end) row[j] = ~0ull;
+            if (l0 + (uint32_t)j * 64u >= n_tile) row[j] = ~0ull;
     } else {
         // validate and pack the raw rows, check unit-major order, accumulate body lengths
         tile_u_first = first_u;
         tile_web = (first_m & 3u) == SEBM25_SRC_WEB;
         // (source, unit) of the row before this wave's first row
         uint64_t carry = wave0 > 0 ? (((uint64_t)(((prev_m & 3u) == SEBM25_SRC_NEWS) ? 1u : 0u) << 32) | prev_u) : 0ull;
+        // the packed row in 32-bit halves: term and source only reach the high word (bit 31 of the
+        // low word for the source when term ids fill 32 bits)
+        const int term_sh = 32 - fmt.term_bits;
+        const uint32_t src_hi = fmt.term_bits < 32 ? 1u << (31 - fmt.term_bits) : 0u;
+        const uint32_t src_lo = fmt.term_bits < 32 ? 0u : 0x80000000u;
+        const bool check_tf = fmt.tf_bits < 32;
+        const int tf_sh = fmt.tf_bits & 31;
     #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
-            const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-            const bool valid = i < end;
+            const bool valid = l0 + (uint32_t)j * 64u < n_tile;
             const uint32_t st = m[j] & 3u, field = m[j] >> 2;
-            const uint32_t src = (st == SEBM25_SRC_NEWS) ? 1u : 0u;
-            uint64_t r = ~0ull;
-            if (valid) {
-                const bool bad = term[j] >= ctx.n_terms || (st != SEBM25_SRC_WEB && st != SEBM25_SRC_NEWS) ||
-                                 unit[j] >= (src ? ctx.n_articles : ctx.n_docs) ||
-                                 (fmt.tf_bits < 32 && (tfv[j] >> fmt.tf_bits) != 0u);
+            const bool news = st == SEBM25_SRC_NEWS;
+            // bitwise, not short-circuit: four compares and mask logic instead of nested branches
+            const bool bad = valid & ((term[j] >= ctx.n_terms) | (st - 1u >= 2u) |
+                                      (unit[j] >= (news ? ctx.n_articles : ctx.n_docs)) |
+                                      (check_tf & ((tfv[j] >> tf_sh) != 0u)));
+            if (__ballot(bad) != 0ull) {  // one scalar branch per round on the good path
                 if (bad) {
                     atomicOr(ctx.err, DEV_ERR_RANGE);
                     // the same key bits as the histogram saw, every later index in range
@@ -374,20 +401,26 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
                     unit[j] &= (uint32_t)((1ull << fmt.unit_bits) - 1ull);
                     tfv[j] = 0;
                 }
-                r = fmt.pack(term[j], src, unit[j], field_code(field), tfv[j]);
             }
-            row[j] = r;
+            // same bits as RowFmt::pack(term, news, unit, field code, tf); field code: 1, 2, else 0
+            const uint32_t fc = field < 3u ? field : 0u;
+            const uint64_t low = ((((uint64_t)(unit[j] >> 30) << 32) | ((unit[j] << 2) | fc)) << fmt.tf_bits) | tfv[j];
+            const uint32_t hi = hi32(low) | (term[j] << term_sh) | (news ? src_hi : 0u);
+            const uint32_t lo = lo32(low) | (news ? src_lo : 0u);
+            row[j] = valid ? (((uint64_t)hi << 32) | lo) : ~0ull;
             // unit-major check: (source, unit) must not decrease from one row to the next
-            const uint64_t ukey = valid ? (((uint64_t)src << 32) | unit[j]) : ~0ull;
+            const uint64_t ukey = valid ? (((uint64_t)(news ? 1u : 0u) << 32) | unit[j]) : ~0ull;
             uint64_t prev = lane_up1(ukey);
             if (lane == 0) prev = carry;
             carry = lane_bcast<63>(ukey);
-            if (valid && ctx.check_order && ukey < prev) atomicOr(ctx.err, DEV_ERR_ORDER);
+            if (ctx.check_order && __ballot(valid && ukey < prev) != 0ull) {
+                if (lane == 0) atomicOr(ctx.err, DEV_ERR_ORDER);
+            }
             // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
-            // one doc: then one lane adds the wave's sum to the tile's LDS counter of that doc.
-            const uint32_t body = (valid && src == 0u && field == SEBM25_FIELD_BODY && unit[j] < ctx.n_docs) ? tfv[j] : 0u;
-            const uint64_t first_key = lane_bcast<0>(ukey);
-            const bool uniform = __all(ukey == first_key);
+            // one doc (every lane but the first has its predecessor's key): then one lane adds the
+            // wave's sum to the tile's LDS counter of that doc.
+            const uint32_t body = (valid & !news & (field == SEBM25_FIELD_BODY) & (unit[j] < ctx.n_docs)) ? tfv[j] : 0u;
+            const bool uniform = (__ballot(ukey != prev) & ~1ull) == 0ull;
             uint32_t add = body;
             bool do_add = body != 0u;
             if (uniform) {
@@ -395,8 +428,8 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
                 do_add = lane == 0 && add != 0u;
             }
             if (do_add) {
-                const uint32_t off = unit[j] - tile_u_first;
-                if (tile_web && unit[j] >= tile_u_first && off < (uint32_t)DL_SPAN)
+                const uint32_t off = unit[j] - tile_u_first;  // wraps to a large value for a doc before the tile's first
+                if (tile_web && off < (uint32_t)DL_SPAN)
                     atomicAdd(&dl_s[off], add);
                 else
                     atomicAdd(&ctx.doc_len[unit[j]], add);
@@ -413,8 +446,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         uint32_t in0_bits = 0, valid_bits = 0;
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
-            const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-            const bool valid = i < end;
+            const bool valid = l0 + (uint32_t)j * 64u < n_tile;
             const uint32_t d = shr_lo32(row[j], shift) & mask;
             dg[j] = d;
             const uint64_t vm = __ballot(valid);
@@ -505,11 +537,9 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
 
     // ---- reorder the tile by digit inside LDS (stable); the match tables and body-length counters
     //      that shared this memory are dead by now
-    const uint32_t n_tile = (uint32_t)(end - tile0);
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
-        const uint64_t i = wave0 + (uint64_t)j * 64u + lane;
-        if (i < end) {
+        if (l0 + (uint32_t)j * 64u < n_tile) {
             const uint32_t d = shr_lo32(row[j], shift) & mask;
             rows_s[whist[wave][d] + rk[j]] = row[j];
         }
