@@ -318,10 +318,10 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(row_ptr, 0xFF, ((size_t)V + 1) * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
-        HIP_TRY(ix, ix->scan_tmp.ensure(row_ptr_fill_tmp_words(V) * 4));
+        HIP_TRY(ix, ix->scan_tmp.ensure(std::max(row_ptr_fill_tmp_words(V), postings_tmp_words(n_chunks)) * 4));
         phase_begin(ix, "postings");
         launch_postings(sorted, R, chunk2, n_chunks, fmt, flags_dev, in->n_docs, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
-                        ix->df_local.as<uint32_t>(), scal, err_dev, ix->stream);
+                        ix->df_local.as<uint32_t>(), scal, ix->scan_tmp.as<uint32_t>(), err_dev, ix->stream);
         phase_end(ix);
         phase_begin(ix, "term_stats");
         launch_row_ptr_fill(row_ptr, V, R, ix->scan_tmp.as<uint32_t>(), ix->stream);

@@ -746,7 +746,8 @@ __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool 
 
 // row_ptr[t] = first slot of term t (left at 0xFFFFFFFF for terms without rows), news_ptr[t] =
 // first news slot of term t (left at 0xFFFFFFFF for terms without news rows), df[t] += web heads of term t (zeroed by
-// the caller), totals[0] += kept postings, totals[1] += web heads, totals[5] += kept web postings.
+// the caller), partials[range] = (kept postings, web heads, kept web postings) of the range, summed into
+// totals[0], [1], [5] by k_postings_totals.
 // Row flags:
 //   head    : first row of its (term, source, unit) run
 //   kept    : head of a news unit, or of a web doc whose status is 'done' (search_service.py:32)
@@ -763,33 +764,48 @@ __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool 
 // Per row the kernel computes one 32-bit word v = tenths(row) | differs-from-predecessor << 31;
 // what a run head needs to know about the rows behind it (do they continue the run, what do they
 // weigh) then comes from three one-lane shifts of v instead of three more rows to decode.
+// lane i <- lane i-1 / lane i+1 of x; the lane at the wave's edge takes `edge` instead
+__device__ __forceinline__ uint32_t lane_up1_edge(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_dn1_edge(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+
 template <bool HAS_FLAGS>
 __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, uint32_t R, uint32_t chunk_rows,
                                                           uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
                                                           uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit,
                                                           uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
-                                                          uint32_t* df, unsigned long long* totals, uint32_t* err) {
-    const uint32_t c = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
+                                                          uint32_t* df, uint4* partials, uint32_t* err) {
+    // the range index is the same for the whole wave: tell the compiler, so that everything derived
+    // from it (bounds, base addresses, loop control) lives in scalar registers
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6)));
     if (c >= n_chunks) return;
     const RowBits rb(fmt);
     const uint32_t lane = lane_id();
     const uint64_t lt = lanemask_lt();
-    const uint32_t begin = c * chunk_rows;  // < R; the host keeps R + 3 * RED_BATCH below 2^32
+    const uint32_t begin = c * chunk_rows;  // < R; the host keeps R + POST_PAD below 2^32
     const uint32_t end = R - begin < chunk_rows ? R : begin + chunk_rows;
     const uint64_t key_lsb = 1ull << fmt.key_shift();
-    // rows behind the last one read as a row of another key; so does the row before row 0
+    // rows behind the last one read as a row of another key; the row before row 0 as one of another term
     const uint64_t behind = rows[R - 1] ^ key_lsb;
-    uint64_t carry = begin ? rows[begin - 1] : rows[0] ^ key_lsb;
+    uint64_t carry = begin ? rows[begin - 1] : rows[0] ^ (1ull << 63);
     uint32_t n_kept = 0, n_wh = 0, n_kept_web = 0;
     // web heads of the term the last rounds consisted of, not yet added to df
     constexpr uint32_t NO_TERM = 0xFFFFFFFFu;
     uint32_t run_term = NO_TERM, run_wh = 0;
+    // (term, source) bits of a row
+    const uint32_t ts_hi = rb.term_hi | rb.src_hi, ts_lo = rb.src_lo;
 
     uint64_t ra[RED_ROUNDS], rb1[RED_ROUNDS], rc[RED_ROUNDS];  // rows of batch b, b + 1, b + 2
     uint32_t da[RED_ROUNDS], db[RED_ROUNDS];                   // doc status of batch b, b + 1
+    // the row array is padded like the slot arrays: loads run up to 3 batches past the last row
+    // without a clamp (what they bring is replaced below before it is looked at)
     auto load_rows = [&](uint32_t b0, uint64_t (&dst)[RED_ROUNDS]) {
+        const uint64_t* p = rows + b0;
 #pragma unroll
-        for (int j = 0; j < RED_ROUNDS; ++j) dst[j] = rows[min(b0 + (uint32_t)j * 64u + lane, R - 1u)];
+        for (int j = 0; j < RED_ROUNDS; ++j) dst[j] = p[(uint32_t)j * 64u + lane];
     };
     auto gather_flags = [&](const uint64_t (&src)[RED_ROUNDS], uint32_t (&dst)[RED_ROUNDS]) {
 #pragma unroll
@@ -799,12 +815,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
             else
                 dst[j] = SEBM25_DOC_DONE;
         }
-    };
-    // v of one round: needs the row before the round's first row
-    auto round_word = [&](uint64_t x, uint64_t before, bool news) -> uint32_t {
-        uint64_t prev = lane_up1(x);
-        if (lane == 0) prev = before;
-        return tenths24(rb, x, news) | (key_differs(rb, x, prev) ? 0x80000000u : 0u);
     };
     load_rows(begin, ra);
     load_rows(begin + RED_BATCH, rb1);
@@ -823,78 +833,82 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
         gather_flags(rb1, db);
         load_rows(b0 + 2 * RED_BATCH, rc);
 
-        // ---- phase 1: the word of every row of the batch, and of the first round behind it
+        // ---- phase 1: per row the word v, whether its term / its (term, source) differ from the
+        //      row before; v also of the first round behind the batch
         uint32_t v[RED_ROUNDS + 1];
-        bool news[RED_ROUNDS];
-        uint32_t big = 0;  // per lane: tf bits from 2^24 up seen in this batch (rows of this range only)
-        uint64_t before = carry;
-        if (b0 + 2u * RED_BATCH > R) {  // only a range's last batches reach behind the last row
+        bool news[RED_ROUNDS], term_new[RED_ROUNDS], ts_new[RED_ROUNDS];
+        uint32_t seen_hi = 0, seen_lo = 0;  // per lane: OR of the batch's rows (for the tf bits from 2^24 up)
+        if (b0 + 2u * RED_BATCH > R) {      // only the last batches reach behind the last row
 #pragma unroll
             for (int j = 0; j < RED_ROUNDS; ++j)
                 if (b0 + (uint32_t)j * 64u + lane >= R) ra[j] = behind;
             if (b0 + RED_BATCH + lane >= R) rb1[0] = behind;
         }
+        uint64_t before = carry;
 #pragma unroll
-        for (int j = 0; j < RED_ROUNDS; ++j) {
-            news[j] = is_news(rb, ra[j]);
-            v[j] = round_word(ra[j], before, news[j]);
-            const uint32_t bits = (hi32(ra[j]) & rb.big_hi) | (lo32(ra[j]) & rb.big_lo);
-            big |= b0 + (uint32_t)j * 64u + lane < end ? bits : 0u;
-            before = lane_bcast<63>(ra[j]);
+        for (int j = 0; j <= RED_ROUNDS; ++j) {
+            const uint64_t x = j < RED_ROUNDS ? ra[j] : rb1[0];
+            const uint32_t dh = hi32(x) ^ lane_up1_edge(hi32(x), hi32(before));
+            const uint32_t dl = lo32(x) ^ lane_up1_edge(lo32(x), lo32(before));
+            const bool nw = is_news(rb, x);
+            const bool differs = ((dh & rb.key_hi) | (dl & rb.key_lo)) != 0u;
+            v[j] = tenths24(rb, x, nw) | (differs ? 0x80000000u : 0u);
+            if (j < RED_ROUNDS) {
+                news[j] = nw;
+                term_new[j] = (dh & rb.term_hi) != 0u;
+                ts_new[j] = ((dh & ts_hi) | (dl & ts_lo)) != 0u;
+                seen_hi |= hi32(x);
+                seen_lo |= lo32(x);
+                before = lane_bcast<63>(x);
+            }
         }
-        v[RED_ROUNDS] = round_word(rb1[0], before, is_news(rb, rb1[0]));
-        if (__ballot(big != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);  // a tf of 2^24 or more: exact weights later
+        carry = before;
+        // a tf of 2^24 or more anywhere in the batch (rows of a neighbouring range included): exact weights later
+        if (__ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
 
         // ---- phase 2: slots, term boundaries, df
+        uint32_t* pu = post_unit + b0;
+        uint32_t* pw = post_w + b0;
+        const uint32_t left = end - b0;  // rows of the range from this batch on
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
-            const uint32_t i = b0 + (uint32_t)j * 64u + lane;
-            const bool valid = i < end;
+            const uint32_t li = (uint32_t)j * 64u + lane;
+            const bool valid = li < left;
             const uint64_t vm = __ballot(valid);
             const uint64_t x0 = ra[j];
             // words of rows i+1 .. i+3: lane shifts; at the wave edge the first lanes of the next round
-            uint32_t n1 = lane_dn1(v[j]);
-            if (lane == 63) n1 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 0);
-            uint32_t n2 = lane_dn1(n1);
-            if (lane == 63) n2 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 1);
-            uint32_t n3 = lane_dn1(n2);
-            if (lane == 63) n3 = (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 2);
+            const uint32_t n1 = lane_dn1_edge(v[j], (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 0));
+            const uint32_t n2 = lane_dn1_edge(n1, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 1));
+            const uint32_t n3 = lane_dn1_edge(n2, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 2));
 
-            const bool head = valid && (v[j] >> 31);
+            const bool head = valid & ((v[j] >> 31) != 0u);
             const uint32_t term = hi32(x0) >> rb.term_sh;
             const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
-            const bool webhead = head && !news[j];
-            const bool kept = head && (news[j] || (da[j] & SEBM25_DOC_DONE));
+            const bool webhead = head & !news[j];
+            const bool kept = head & (news[j] | ((da[j] & SEBM25_DOC_DONE) != 0u));
             const uint64_t km = __ballot(kept), wm = __ballot(webhead);
-            // term and source of the row before (lane shifts must run with every lane active)
-            uint32_t pterm = lane_up1(term), pnews = lane_up1(news[j] ? 1u : 0u);
-            if (lane == 0) {
-                pterm = hi32(carry) >> rb.term_sh;
-                pnews = is_news(rb, carry) ? 1u : 0u;
-            }
-            if (head) {
-                const bool new_term = i == 0u || term != pterm;
-                if (new_term) row_ptr[term] = i;  // terms without rows are filled in by k_row_ptr_fill
-                if (news[j] && (new_term || !pnews)) news_ptr[term] = i;
-            }
-            carry = lane_bcast<63>(x0);
+            // a row whose term differs from the row before starts the term's slots (terms without rows
+            // are filled in by k_row_ptr_fill); its first news row starts the term's news slots
+            if (valid & term_new[j]) row_ptr[term] = b0 + li;
+            if (valid & news[j] & ts_new[j]) news_ptr[term] = b0 + li;
             // a run of up to three rows (title, description, body) with tf < 2^24 each cannot overflow;
             // longer runs (not produced by the reference's writers) are left to k_postings_fixup
-            const bool same1 = !(n1 >> 31), same2 = same1 && !(n2 >> 31), same3 = same2 && !(n3 >> 31);
-            if (__ballot(kept && same3) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
+            const bool same1 = !(n1 >> 31), same2 = same1 & !(n2 >> 31), same3 = same2 & !(n3 >> 31);
+            if (__ballot(kept & same3) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
             const uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
-            post_unit[i] = unit;
-            post_w[i] = kept ? w : POST_HOLE;
+            pu[li] = unit;
+            pw[li] = kept ? w : POST_HOLE;
             n_kept += (uint32_t)__popcll(km);
             n_wh += (uint32_t)__popcll(wm);
             n_kept_web += (uint32_t)__popcll(km & wm);
 
             // df: web heads per term.  Rounds of a single term (the long lists) only extend a running
             // count; a round with several terms adds one count per term segment.
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
+            const uint64_t starts = (__ballot(term_new[j]) | 1ull) & vm;  // first lanes of the round's term segments
             if (vm == 0) {
                 // nothing of this round lies inside the range
-            } else if (__all(!valid || term == t0)) {
+            } else if (starts == 1ull) {
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
                 if (t0 != run_term) {
                     if (lane == 0 && run_wh) atomicAdd(&df[run_term], run_wh);
                     run_term = t0;
@@ -905,10 +919,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
                 if (lane == 0 && run_wh) atomicAdd(&df[run_term], run_wh);
                 run_term = NO_TERM;
                 run_wh = 0;
-                const uint32_t tprev = lane_up1(term), tnext = lane_dn1(term);
-                const uint64_t starts = __ballot(valid && (lane == 0 || term != tprev));
-                const bool next_valid = lane < 63u && ((vm >> (lane + 1u)) & 1ull);
-                if (valid && (!next_valid || tnext != term)) {
+                // the last lane of every segment adds the segment's web heads
+                const uint64_t ends = vm & ((starts >> 1) | ~(vm >> 1));
+                if ((ends >> lane) & 1ull) {
                     const uint64_t upto = lt | (1ull << lane);
                     const int s0 = 63 - __clzll((long long)(starts & upto));  // first lane of this lane's term
                     const uint32_t cnt = (uint32_t)__popcll(wm & upto & ~((1ull << s0) - 1ull));
@@ -925,9 +938,37 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
     }
     if (lane == 0) {
         if (run_wh) atomicAdd(&df[run_term], run_wh);
-        if (n_kept) atomicAdd(&totals[0], (unsigned long long)n_kept);
-        if (n_wh) atomicAdd(&totals[1], (unsigned long long)n_wh);
-        if (n_kept_web) atomicAdd(&totals[5], (unsigned long long)n_kept_web);
+        // the range's counts go to a slot of their own: thousands of atomics on one address would
+        // queue up at one memory channel (34 ns each, measured) and hold back the traffic through it
+        partials[c] = make_uint4(n_kept, n_wh, n_kept_web, 0u);
+    }
+}
+
+// totals[0] += kept postings, totals[1] += web heads, totals[5] += kept web postings over all ranges
+__global__ __launch_bounds__(1024) void k_postings_totals(const uint4* partials, uint32_t n_chunks, unsigned long long* totals) {
+    __shared__ unsigned long long sm[3][16];
+    unsigned long long a = 0, b = 0, c = 0;
+    for (uint32_t i = threadIdx.x; i < n_chunks; i += 1024u) {
+        const uint4 p = partials[i];
+        a += p.x;
+        b += p.y;
+        c += p.z;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+        c += __shfl_down(c, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        sm[0][threadIdx.x >> 6] = a;
+        sm[1][threadIdx.x >> 6] = b;
+        sm[2][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += sm[threadIdx.x][w];
+        if (t) atomicAdd(&totals[threadIdx.x == 2 ? 5 : threadIdx.x], t);
     }
 }
 
@@ -965,19 +1006,23 @@ void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_
 
 void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
                      const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
-                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df, uint64_t* totals, uint32_t* err,
+                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df, uint64_t* totals, uint32_t* tmp, uint32_t* err,
                      hipStream_t st) {
     if (R == 0) return;
+    uint4* partials = reinterpret_cast<uint4*>(tmp);  // postings_tmp_words(n_chunks) words
     const uint32_t wpb = RED_THREADS / 64;
     const dim3 grid((n_chunks + wpb - 1) / wpb), block(RED_THREADS);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(totals);
     if (doc_flags && n_docs)
         hipLaunchKernelGGL(k_postings<true>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
-                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, tot, err);
+                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, partials, err);
     else
         hipLaunchKernelGGL(k_postings<false>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
-                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, tot, err);
+                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, partials, err);
+    hipLaunchKernelGGL(k_postings_totals, dim3(1), dim3(1024), 0, st, partials, n_chunks, tot);
 }
+
+size_t postings_tmp_words(uint32_t n_chunks) { return (size_t)n_chunks * 4; }
 
 // Terms without rows: row_ptr[t] = row_ptr of the next term that has rows, row_ptr[n_terms] = R.
 // First a backward minimum scan inside blocks of 1024 entries, then entries whose block holds

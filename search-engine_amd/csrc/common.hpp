@@ -99,7 +99,7 @@ constexpr int SORT_GROUP = 16;        // chunks per histogram workgroup
 constexpr int RED_THREADS = 256;
 constexpr int RED_ROUNDS = 4;                 // 64-row rounds a wave loads before it processes them
 constexpr int RED_BATCH = 64 * RED_ROUNDS;
-constexpr int POST_PAD = 2 * RED_BATCH;       // slack entries behind each posting slot array
+constexpr int POST_PAD = 4 * RED_BATCH;       // slack entries behind each posting slot array and the sorted rows
 constexpr uint64_t MAX_ROWS = 0xFFFFF000ull;  // row indices plus a few batches of look-ahead stay 32-bit
 
 struct BuildCtx {
@@ -129,7 +129,9 @@ void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStrea
 void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
                      const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
                      uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
-                     uint64_t* totals /* [0] kept, [1] web heads, [5] kept web; zeroed */, uint32_t* err, hipStream_t st);
+                     uint64_t* totals /* [0] kept, [1] web heads, [5] kept web; zeroed */,
+                     uint32_t* tmp /* postings_tmp_words(n_chunks) words, 16-byte aligned */, uint32_t* err, hipStream_t st);
+size_t postings_tmp_words(uint32_t n_chunks);
 // fills row_ptr entries of terms without rows (0xFFFFFFFF) and sets row_ptr[n_terms] = R
 size_t row_ptr_fill_tmp_words(uint32_t n_terms);
 void launch_row_ptr_fill(uint32_t* row_ptr, uint32_t n_terms, uint64_t R, uint32_t* tmp, hipStream_t st);
