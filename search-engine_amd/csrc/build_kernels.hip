@@ -46,6 +46,13 @@ __device__ __forceinline__ uint64_t lane_up1(uint64_t x) {
 __device__ __forceinline__ uint64_t lane_dn1(uint64_t x) {
     return ((uint64_t)lane_dn1((uint32_t)(x >> 32)) << 32) | lane_dn1((uint32_t)x);
 }
+// lane i <- lane i-1 / lane i+1 of x; the lane at the wave's edge takes `edge` instead
+__device__ __forceinline__ uint32_t lane_up1_edge(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_dn1_edge(uint32_t x, uint32_t edge) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
 template <int L>
 __device__ __forceinline__ uint64_t lane_bcast(uint64_t x) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), L) << 32) |
@@ -384,15 +391,23 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         const uint32_t src_lo = fmt.term_bits < 32 ? 0u : 0x80000000u;
         const bool check_tf = fmt.tf_bits < 32;
         const int tf_sh = fmt.tf_bits & 31;
+        // Lanes behind the tile's end hold copies of its last row (clamped loads): they pass every
+        // check the last row passes and continue its (source, unit) run, so the loop below needs no
+        // validity test; their tf is zeroed here and their row replaced after the loop.
+        if (n_tile < (uint32_t)SORT_TILE) {
+    #pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j)
+                if (l0 + (uint32_t)j * 64u >= n_tile) tfv[j] = 0;
+        }
+        uint32_t carry_u = lo32(carry), carry_s = hi32(carry);
     #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
-            const bool valid = l0 + (uint32_t)j * 64u < n_tile;
             const uint32_t st = m[j] & 3u, field = m[j] >> 2;
             const bool news = st == SEBM25_SRC_NEWS;
             // bitwise, not short-circuit: four compares and mask logic instead of nested branches
-            const bool bad = valid & ((term[j] >= ctx.n_terms) | (st - 1u >= 2u) |
-                                      (unit[j] >= (news ? ctx.n_articles : ctx.n_docs)) |
-                                      (check_tf & ((tfv[j] >> tf_sh) != 0u)));
+            const bool bad = (term[j] >= ctx.n_terms) | (st - 1u >= 2u) |
+                             (unit[j] >= (news ? ctx.n_articles : ctx.n_docs)) |
+                             (check_tf & ((tfv[j] >> tf_sh) != 0u));
             if (__ballot(bad) != 0ull) {  // one scalar branch per round on the good path
                 if (bad) {
                     atomicOr(ctx.err, DEV_ERR_RANGE);
@@ -407,20 +422,22 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             const uint64_t low = ((((uint64_t)(unit[j] >> 30) << 32) | ((unit[j] << 2) | fc)) << fmt.tf_bits) | tfv[j];
             const uint32_t hi = hi32(low) | (term[j] << term_sh) | (news ? src_hi : 0u);
             const uint32_t lo = lo32(low) | (news ? src_lo : 0u);
-            row[j] = valid ? (((uint64_t)hi << 32) | lo) : ~0ull;
+            row[j] = ((uint64_t)hi << 32) | lo;
             // unit-major check: (source, unit) must not decrease from one row to the next
-            const uint64_t ukey = valid ? (((uint64_t)(news ? 1u : 0u) << 32) | unit[j]) : ~0ull;
-            uint64_t prev = lane_up1(ukey);
-            if (lane == 0) prev = carry;
-            carry = lane_bcast<63>(ukey);
-            if (ctx.check_order && __ballot(valid && ukey < prev) != 0ull) {
+            const uint32_t s = news ? 1u : 0u;
+            const uint32_t prev_u = lane_up1_edge(unit[j], carry_u), prev_s = lane_up1_edge(s, carry_s);
+            carry_u = (uint32_t)__builtin_amdgcn_readlane((int)unit[j], 63);
+            carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+            const bool same = (unit[j] == prev_u) & (s == prev_s);
+            const bool less = (s < prev_s) | ((s == prev_s) & (unit[j] < prev_u));
+            if (ctx.check_order && __ballot(less) != 0ull) {
                 if (lane == 0) atomicOr(ctx.err, DEV_ERR_ORDER);
             }
             // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
             // one doc (every lane but the first has its predecessor's key): then one lane adds the
             // wave's sum to the tile's LDS counter of that doc.
-            const uint32_t body = (valid & !news & (field == SEBM25_FIELD_BODY) & (unit[j] < ctx.n_docs)) ? tfv[j] : 0u;
-            const bool uniform = (__ballot(ukey != prev) & ~1ull) == 0ull;
+            const uint32_t body = (!news & (field == SEBM25_FIELD_BODY) & (unit[j] < ctx.n_docs)) ? tfv[j] : 0u;
+            const bool uniform = (__ballot(!same) & ~1ull) == 0ull;
             uint32_t add = body;
             bool do_add = body != 0u;
             if (uniform) {
@@ -434,6 +451,11 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
                 else
                     atomicAdd(&ctx.doc_len[unit[j]], add);
             }
+        }
+        if (n_tile < (uint32_t)SORT_TILE) {
+    #pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j)
+                if (l0 + (uint32_t)j * 64u >= n_tile) row[j] = ~0ull;
         }
 
     }
@@ -764,14 +786,6 @@ __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool 
 // Per row the kernel computes one 32-bit word v = tenths(row) | differs-from-predecessor << 31;
 // what a run head needs to know about the rows behind it (do they continue the run, what do they
 // weigh) then comes from three one-lane shifts of v instead of three more rows to decode.
-// lane i <- lane i-1 / lane i+1 of x; the lane at the wave's edge takes `edge` instead
-__device__ __forceinline__ uint32_t lane_up1_edge(uint32_t x, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t lane_dn1_edge(uint32_t x, uint32_t edge) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-}
-
 template <bool HAS_FLAGS>
 __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, uint32_t R, uint32_t chunk_rows,
                                                           uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
