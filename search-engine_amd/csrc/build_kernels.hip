@@ -1093,10 +1093,12 @@ void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news
 
 // N, and the numerator / denominator of AVG(word_count), over documents with status 'done'
 // (bm25_stats.py:9-13).  totals3 = {n_done, n_wc, sum_wc}, zeroed by the caller.
-__global__ __launch_bounds__(256) void k_doc_stats(const uint32_t* word_count, const uint32_t* doc_len,
+// Few, large workgroups: every workgroup ends with three atomics on the same three words, and
+// same-address atomics are served one after the other.
+__global__ __launch_bounds__(1024) void k_doc_stats(const uint32_t* word_count, const uint32_t* doc_len,
                                                    const uint8_t* doc_flags, uint32_t n_docs,
                                                    unsigned long long* totals3) {
-    __shared__ unsigned long long sh[3][4];
+    __shared__ unsigned long long sh[3][16];
     unsigned long long nd = 0, nw = 0, sw = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += gridDim.x * blockDim.x) {
         const uint32_t fl = doc_flags ? doc_flags[d] : SEBM25_DOC_DONE;
@@ -1119,7 +1121,8 @@ __global__ __launch_bounds__(256) void k_doc_stats(const uint32_t* word_count, c
     }
     __syncthreads();
     if (threadIdx.x < 3) {
-        unsigned long long s = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+        unsigned long long s = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64u; ++w) s += sh[threadIdx.x][w];
         if (s) atomicAdd(&totals3[threadIdx.x], s);
     }
 }
@@ -1127,8 +1130,8 @@ __global__ __launch_bounds__(256) void k_doc_stats(const uint32_t* word_count, c
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags, uint32_t n_docs,
                       uint64_t* totals3, hipStream_t st) {
     if (n_docs == 0) return;
-    const uint32_t blocks = min((n_docs + 255u) / 256u, 2048u);
-    hipLaunchKernelGGL(k_doc_stats, dim3(blocks), dim3(256), 0, st, word_count, doc_len, doc_flags, n_docs,
+    const uint32_t blocks = min((n_docs + 1023u) / 1024u, 256u);
+    hipLaunchKernelGGL(k_doc_stats, dim3(blocks), dim3(1024), 0, st, word_count, doc_len, doc_flags, n_docs,
                        reinterpret_cast<unsigned long long*>(totals3));
 }
 
