@@ -63,8 +63,35 @@ struct TopK {
     static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + (HAS_TIE ? 4 : 0) + 1) + 15) / 16 * 16; }
     __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
 
-    // wave-wide bitonic sort of all CAP slots (dead slots hold the worst key), best first
+    // one compare-exchange of the sorting network: the better entry goes to slot lo
+    __device__ __forceinline__ void order(uint32_t lo, uint32_t hi) {
+        const uint64_t klo = key[lo], khi = key[hi];
+        const uint32_t ul = unit[lo], uh = unit[hi];
+        const uint32_t tlo = HAS_TIE ? tie_[lo] : ul, thi = HAS_TIE ? tie_[hi] : uh;
+        if (better(khi, thi, klo, tlo)) {
+            key[lo] = khi;
+            key[hi] = klo;
+            if (HAS_TIE) {
+                tie_[lo] = thi;
+                tie_[hi] = tlo;
+            }
+            unit[lo] = uh;
+            unit[hi] = ul;
+            const unsigned char ml = mat[lo], mh = mat[hi];
+            mat[lo] = mh;
+            mat[hi] = ml;
+        }
+    }
+
+    // Wave-wide bitonic sort of all CAP slots (dead slots hold the worst key), best first.  Every
+    // comparator puts the better entry into the lower slot (a merge starts with a mirror stage
+    // instead of sorting half the blocks the other way), so the network for the next power of two
+    // sorts any CAP: comparators that reach past CAP would compare with a worst entry that stays
+    // where it is, and are skipped.
     __device__ void cut(uint32_t k) {
+        constexpr uint32_t P = CAP <= 64 ? 64 : CAP <= 128 ? 128 : CAP <= 256 ? 256 : CAP <= 512 ? 512 : CAP <= 1024 ? 1024
+                               : CAP <= 2048 ? 2048 : 4096;
+        static_assert(CAP <= 4096 && CAP % 64 == 0, "candidate buffer sizes are multiples of 64 up to 4096");
         const uint32_t lane = lane_id();
         for (uint32_t i = n + lane; i < CAP; i += 64) {
             key[i] = 0;
@@ -73,29 +100,21 @@ struct TopK {
             mat[i] = 0;
         }
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t size = 2; size <= CAP; size <<= 1) {
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (uint32_t e = lane; e < CAP / 2; e += 64) {
+        for (uint32_t lg = 1; (1u << lg) <= P; ++lg) {
+            const uint32_t size = 1u << lg, half = size >> 1;
+#pragma unroll 1
+            for (uint32_t e = lane; e < P / 2; e += 64) {  // mirror stage
+                const uint32_t blk = (e >> (lg - 1u)) << lg, i = e & (half - 1u);
+                const uint32_t lo = blk + i, hi = blk + size - 1u - i;
+                if (hi < CAP) order(lo, hi);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t stride = half >> 1; stride > 0; stride >>= 1) {
+#pragma unroll 1
+                for (uint32_t e = lane; e < P / 2; e += 64) {
                     const uint32_t lo = ((e & ~(stride - 1)) << 1) | (e & (stride - 1));
                     const uint32_t hi = lo | stride;
-                    const bool desc = (lo & size) == 0;  // block direction
-                    const uint64_t klo = key[lo], khi = key[hi];
-                    const uint32_t ul = unit[lo], uh = unit[hi];
-                    const uint32_t tlo = HAS_TIE ? tie_[lo] : ul, thi = HAS_TIE ? tie_[hi] : uh;
-                    const bool hi_first = better(khi, thi, klo, tlo);
-                    if (hi_first == desc) {
-                        key[lo] = khi;
-                        key[hi] = klo;
-                        if (HAS_TIE) {
-                            tie_[lo] = thi;
-                            tie_[hi] = tlo;
-                        }
-                        unit[lo] = uh;
-                        unit[hi] = ul;
-                        const unsigned char ml = mat[lo], mh = mat[hi];
-                        mat[lo] = mh;
-                        mat[hi] = ml;
-                    }
+                    if (hi < CAP) order(lo, hi);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -406,8 +425,11 @@ constexpr int HASH_SLOTS = 512;
 constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
 
 // HAS_RANK: url ranks were given (a.url_rank != null); without them a unit's tie-break key is its id
+// waves per SIMD the register budget is held to: what the kernel's LDS allows anyway
+constexpr int hash_waves_per_simd(int cap) { return cap <= 128 ? 4 : cap <= 512 ? 3 : 1; }
+
 template <int CAP, bool HAS_RANK>
-__global__ __launch_bounds__(64) void k_score_hash(ScoreArgs a) {
+__global__ __launch_bounds__(64, hash_waves_per_simd(CAP)) void k_score_hash(ScoreArgs a) {
     __shared__ __align__(16) double acc[HASH_SLOTS];
     __shared__ uint32_t tag[HASH_SLOTS];
     __shared__ unsigned char cnt[HASH_SLOTS];
@@ -585,12 +607,12 @@ void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t s
         dim3 grid(n_fast), block(64);
         if (a.url_rank) {
             if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, true>), grid, block, 0, st, a);
-            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<512, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_hash<4096, true>), grid, block, 0, st, a);
+            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_hash<2112, true>), grid, block, 0, st, a);
         } else {
             if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, false>), grid, block, 0, st, a);
-            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<512, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_hash<4096, false>), grid, block, 0, st, a);
+            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_hash<2112, false>), grid, block, 0, st, a);
         }
     } else if (n_fast) {
         dim3 grid(n_fast), block(64);
@@ -599,10 +621,10 @@ void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t s
             else if (window <= 1024) hipLaunchKernelGGL((k_score_fast<128, 1024>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_score_fast<128, 2048>), grid, block, 0, st, a);
         } else if (a.k <= 256) {
-            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<512, 1024>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_fast<512, 2048>), grid, block, 0, st, a);
+            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<320, 1024>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_score_fast<320, 2048>), grid, block, 0, st, a);
         } else {
-            hipLaunchKernelGGL((k_score_fast<4096, 1024>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_score_fast<2112, 1024>), grid, block, 0, st, a);
         }
     }
     if (a.n_items > n_fast) {
@@ -613,9 +635,9 @@ void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t s
         if (a.k <= 64)
             hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, b);
         else if (a.k <= 256)
-            hipLaunchKernelGGL(k_score<512>, grid, block, 0, st, b);
+            hipLaunchKernelGGL(k_score<320>, grid, block, 0, st, b);
         else
-            hipLaunchKernelGGL(k_score<4096>, grid, block, 0, st, b);
+            hipLaunchKernelGGL(k_score<2112>, grid, block, 0, st, b);
     }
 }
 
@@ -627,9 +649,9 @@ void launch_merge(const MergeArgs& a, hipStream_t st) {
     if (a.k <= 64)
         hipLaunchKernelGGL(k_merge<128>, grid, block, 0, st, a);
     else if (a.k <= 256)
-        hipLaunchKernelGGL(k_merge<512>, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_merge<320>, grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL(k_merge<4096>, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_merge<2112>, grid, block, 0, st, a);
 }
 
 }  // namespace sebm25
