@@ -465,7 +465,8 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         uint32_t* tab = mtab + wave * (2u << MATCH_TAB_BITS);
         uint32_t dg[SORT_ITEMS];
         uint64_t cand[SORT_ITEMS], m0[SORT_ITEMS];
-        uint32_t in0_bits = 0, valid_bits = 0;
+        uint32_t d0s[SORT_ITEMS];  // wave-uniform: the digit of the round's first valid lane
+        const uint32_t rows_left = n_tile > l0 ? n_tile - l0 : 0u;  // round j's row is valid iff 64 j < rows_left
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const bool valid = l0 + (uint32_t)j * 64u < n_tile;
@@ -474,11 +475,10 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             const uint64_t vm = __ballot(valid);
             // the group of the first valid lane (the hot digit of skewed or sorted rows) by one compare
             const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, vm ? __ffsll((unsigned long long)vm) - 1 : 0);
+            d0s[j] = d0;
             const bool in0 = valid && d == d0;
             m0[j] = __ballot(in0);
             const bool rest = valid && !in0;
-            valid_bits |= (valid ? 1u : 0u) << j;
-            in0_bits |= (in0 ? 1u : 0u) << j;
             const uint32_t slot = (d & ((1u << MATCH_TAB_BITS) - 1u)) * 2u;
             cand[j] = 0;
             if (rest) atomicOr(&tab[slot + (lane >> 5)], 1u << (lane & 31u));
@@ -490,14 +490,14 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         }
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
-            const bool valid = (valid_bits >> j) & 1u;
+            const bool valid = (uint32_t)j * 64u < rows_left;  // recomputed: cheaper than carrying a bit per round
             uint64_t peers = cand[j];  // lanes that share the low digit bits: settle the high bits
             for (int b = MATCH_TAB_BITS; b < bits; ++b) {
                 const bool one = (dg[j] >> b) & 1u;
                 const uint64_t bal = __ballot(one);
                 peers &= one ? bal : ~bal;
             }
-            if ((in0_bits >> j) & 1u) peers = m0[j];
+            if (valid && dg[j] == d0s[j]) peers = m0[j];
             // every lane of a digit group reads the group's running count (one address: a broadcast),
             // then its first lane adds the group's size
             uint32_t old = 0;
