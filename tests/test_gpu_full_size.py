@@ -22,6 +22,12 @@ pytestmark = pytest.mark.gpu
 DOCS, VOCAB = int(os.environ.get("SEBM25_TEST_DOCS", 1_000_000)), 500_000   # the env override is for one-off runs at larger sizes
 
 
+def pieces(n, step=1 << 30):
+    """Slices of at most 2^30 rows: torch's mask indexing miscounts on tensors of 2^31 elements and more."""
+    for lo in range(0, n, step):
+        yield slice(lo, min(n, lo + step))
+
+
 @pytest.fixture(scope="module")
 def full(gpu_index_factory):
     import torch
@@ -61,10 +67,13 @@ def test_sampled_terms_against_raw_rows(full):
     rng = np.random.default_rng(11)
     sample = [0, 1, 7, 99, 100, 1023, 1024, 4095, VOCAB - 1] + [int(x) for x in rng.integers(0, VOCAB, 40)]
     for t in sample:
-        sel = term == t
-        units = unit[sel]
-        df = int(torch.unique(units).numel())
-        assert int(st["term_rows"][t]) == int(sel.sum().item()), t
+        rows, units = 0, []
+        for p in pieces(n):
+            sel = term[p] == t
+            rows += int(sel.sum().item())
+            units.append(unit[p][sel])
+        df = int(torch.unique(torch.cat(units)).numel())
+        assert int(st["term_rows"][t]) == rows, t
         assert int(st["df"][t]) == df, t
         want = math.log1p((DOCS - df + 0.5) / (df + 0.5))
         assert abs(st["idf"][t] - want) <= 1e-14 * abs(want), t
@@ -79,20 +88,20 @@ def test_sampled_queries_against_dense_scatter_add(full):
     qs = se.gen_queries(20260228, VOCAB, 12, 3, 100)
     k = 10
     out = ix.search(qs, k)
-    field = (meta >> 2).to(torch.int64)
-    w_field = torch.ones(n, dtype=torch.float64, device=term.device)   # W = {1: 3.2, 2: 1.7, else 1.0} in double
-    w_field[field == 1] = 3.2
-    w_field[field == 2] = 1.7
+    w_table = torch.ones(64, dtype=torch.float64, device=term.device)   # W = {1: 3.2, 2: 1.7, else 1.0} in double
+    w_table[1] = 3.2
+    w_table[2] = 1.7
     for qi, q in enumerate(qs):
         score = torch.zeros(DOCS, dtype=torch.float64, device=term.device)
         matched = torch.zeros(DOCS, dtype=torch.int32, device=term.device)
         for t in dict.fromkeys(int(x) for x in q):
-            sel = term == t
-            u = unit[sel].long()
-            # the SQL formula row by row: (tf * idf) * W[field]
-            score.index_add_(0, u, (tf[sel].double() * float(idf[t])) * w_field[sel])
             seen = torch.zeros(DOCS, dtype=torch.int32, device=term.device)
-            seen[u] = 1
+            for p in pieces(n):
+                sel = term[p] == t
+                u = unit[p][sel].long()
+                # the SQL formula row by row: (tf * idf) * W[field]
+                score.index_add_(0, u, (tf[p][sel].double() * float(idf[t])) * w_table[(meta[p][sel] >> 2).long()])
+                seen[u] = 1
             matched += seen
         hit = matched > 0
         n_hit = int(hit.sum().item())
