@@ -142,30 +142,36 @@ int flush_h2d(sebm25_index* ix) {
     hipError_t errs[THREADS];
     std::thread th[THREADS];
     const int dev = ix->device;
+    auto work = [&](int t) {
+        hipError_t e = hipSetDevice(dev);
+        hipStream_t s = nullptr;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        for (const H2DJob& j : jobs) {
+            if (e != hipSuccess) break;
+            // slice t of every array, cut at 4 KB multiples
+            const size_t per = ((j.bytes + THREADS - 1) / THREADS + 4095) / 4096 * 4096;
+            const size_t off = std::min(j.bytes, per * (size_t)t), len = std::min(j.bytes - off, per);
+            if (len)
+                e = hipMemcpyAsync(static_cast<char*>(j.dst) + off, static_cast<const char*>(j.src) + off, len,
+                                   hipMemcpyHostToDevice, s);
+        }
+        if (s) {
+            const hipError_t e2 = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = e2;
+            (void)hipStreamDestroy(s);
+        }
+        errs[t] = e;
+    };
     for (int t = 0; t < THREADS; ++t) {
         errs[t] = hipSuccess;
-        th[t] = std::thread([&, t]() {
-            hipError_t e = hipSetDevice(dev);
-            hipStream_t s = nullptr;
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-            for (const H2DJob& j : jobs) {
-                if (e != hipSuccess) break;
-                // slice t of every array, cut at 4 KB multiples
-                const size_t per = ((j.bytes + THREADS - 1) / THREADS + 4095) / 4096 * 4096;
-                const size_t off = std::min(j.bytes, per * (size_t)t), len = std::min(j.bytes - off, per);
-                if (len)
-                    e = hipMemcpyAsync(static_cast<char*>(j.dst) + off, static_cast<const char*>(j.src) + off, len,
-                                       hipMemcpyHostToDevice, s);
-            }
-            if (s) {
-                const hipError_t e2 = hipStreamSynchronize(s);
-                if (e == hipSuccess) e = e2;
-                (void)hipStreamDestroy(s);
-            }
-            errs[t] = e;
-        });
+        try {
+            th[t] = std::thread(work, t);
+        } catch (...) {  // no thread to be had: this slice is copied here, nothing crosses the C boundary
+            work(t);
+        }
     }
-    for (int t = 0; t < THREADS; ++t) th[t].join();
+    for (int t = 0; t < THREADS; ++t)
+        if (th[t].joinable()) th[t].join();
     for (int t = 0; t < THREADS; ++t) HIP_TRY(ix, errs[t]);
     return SEBM25_OK;
 }

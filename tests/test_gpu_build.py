@@ -138,6 +138,39 @@ def test_gpu_generator_matches_cpu_generator(gpu_index_factory):
     np.testing.assert_array_equal(se.gen_queries(20260228, 5000, 50, 3, 100),
                                   O.gen_queries(20260228, 5000, O.zipf_cdf(5000), 100, 50, 3))
 
+def test_large_host_arrays_are_staged_like_device_arrays(gpu_index_factory):
+    """Host arrays of 64 MB and more are copied in by several threads, each a slice of every array:
+    the index must come out the same as from the device-resident arrays."""
+    import torch
+
+    ix = gpu_index_factory()
+    spec = se.make_spec(n_terms=40_000, n_docs=25_000, n_articles=500)
+    n = ix.gen_corpus_rows(spec)
+    assert n * 13 > 64 << 20
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    u = torch.empty_like(t)
+    f = torch.empty_like(t)
+    m = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wc = torch.empty(25_000, dtype=torch.int32, device="cuda")
+    ix.gen_corpus(spec, t, u, f, m, wc)
+    ix.build(t, u, f, m, 40_000, 25_000, 500, wc)
+    host = [x.cpu().numpy().view(np.uint32) for x in (t, u, f)] + [m.cpu().numpy(), wc.cpu().numpy().view(np.uint32)]
+    ix2 = gpu_index_factory()
+    ix2.build(host[0], host[1], host[2], host[3], 40_000, 25_000, 500, host[4])
+    a, b = ix.stats(), ix2.stats()
+    for key in ("df", "term_rows"):
+        np.testing.assert_array_equal(a[key], b[key])
+    np.testing.assert_array_equal(a["idf"].view(np.uint64), b["idf"].view(np.uint64))
+    np.testing.assert_array_equal(ix.doc_len(), ix2.doc_len())
+    assert ix.info().n_postings == ix2.info().n_postings
+    qs = se.gen_queries(5, 40_000, 200, 3, 100)
+    for src in (se.SRC_WEB, se.SRC_NEWS):
+        ra, rb = ix.search(qs, 10, source=src), ix2.search(qs, 10, source=src)
+        np.testing.assert_array_equal(ra["unit"], rb["unit"])
+        np.testing.assert_array_equal(ra["score"].view(np.uint64), rb["score"].view(np.uint64))
+    ix2.close()
+
+
 def test_long_runs_and_huge_tf_take_the_exact_path(gpu_index_factory):
     """More than three rows of one (term, doc) (fields the reference's writers never produce) and
     term frequencies of 2^24 and more leave the streaming kernel's fast path: same exact weights."""
