@@ -38,7 +38,8 @@ struct sebm25_index {
     RowFmt fmt{1, 1, 59};
     uint32_t n_pass = 0;
     int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
-    int score_window = 0;           // 0: posting-space steps with hashed accumulators; 512 | 1024 | 2048: unit-id windows of that size (SEBM25_SCORE_WINDOW)
+    int score_impl = 0;             // 0: stepwise kernels with bound-based filtering; 1: the older hashed-accumulator kernel (SEBM25_SCORE_IMPL=hash)
+    bool big_weights = false;       // some posting weight needs more than 16 bits: queries take the general kernel
     uint64_t P = 0, P_web = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
     sebm25_doc_totals local_totals{}, used_totals{};
@@ -417,6 +418,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
                                         "source_type, a tf too wide for the packed row, or a posting weight above 2^32 - 2 tenths");
     if (dev_err & DEV_ERR_ORDER)
         return fail(ix, SEBM25_E_ORDER, "build: rows were declared unit-major (SEBM25_ROWS_UNIT_MAJOR) but are not");
+    ix->big_weights = (dev_err & DEV_BIG_WEIGHT) != 0;
     ix->P = h[0];
     ix->WH = h[1];
     ix->P_web = h[5];
@@ -448,7 +450,7 @@ int sebm25_create(int device, sebm25_index** out) {
     sebm25_index* ix = new (std::nothrow) sebm25_index();
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
-    if (const char* e = getenv("SEBM25_SCORE_WINDOW")) ix->score_window = atoi(e) > 1024 ? 2048 : atoi(e) > 512 ? 1024 : atoi(e) > 0 ? 512 : 0;
+    if (const char* e = getenv("SEBM25_SCORE_IMPL")) ix->score_impl = strcmp(e, "hash") == 0 ? 1 : 0;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     *out = ix;
     return SEBM25_OK;
@@ -758,25 +760,32 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
             plan.push_back({it, q_len[q] / ns});
         }
     }
-    // fast-path items (few lists) first, each group longest first so the tail of the launch is short
-    // work; a counting sort on the length's bit count and its next four bits (order within 6 %),
-    // linear in the item count
-    const uint32_t fast_t = score_fast_max_terms();
+    // items grouped by their number of lists (1 .. fast_t, then everything longer), each group longest
+    // first so the tail of a launch is short work; a counting sort on the length's bit count and its
+    // next four bits (order within 6 %), linear in the item count
+    const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
     std::vector<QItem> items(plan.size());
-    uint32_t n_fast = 0;
+    std::vector<uint32_t> n_by_t(score_fast_max_terms() + 1, 0);
     {
         constexpr uint32_t SUB = 16, PER_GROUP = 65 * SUB;
-        auto bucket_of = [fast_t](const Planned& p) -> uint32_t {
+        const uint32_t n_groups = score_fast_max_terms() + 1;
+        // a query without a matching term still needs its (empty) result row written: the general kernel does that
+        auto group_of = [&](const Planned& p) -> uint32_t {
+            return p.it.n_terms >= 1u && p.it.n_terms <= fast_t ? p.it.n_terms - 1u : n_groups - 1u;
+        };
+        auto bucket_of = [&](const Planned& p) -> uint32_t {
             uint32_t bits = 0;
             for (uint64_t l = p.len; l; l >>= 1) ++bits;  // 0..64
             const uint32_t frac = bits > 4 ? (uint32_t)(p.len >> (bits - 5)) & (SUB - 1) : (uint32_t)p.len & (SUB - 1);
             const uint32_t key = bits * SUB + frac;        // grows with the length
-            return (p.it.n_terms <= fast_t ? 0u : PER_GROUP) + (PER_GROUP - 1u - key);
+            return group_of(p) * PER_GROUP + (PER_GROUP - 1u - key);
         };
-        std::vector<uint32_t> start(2 * PER_GROUP + 1, 0);
-        for (const Planned& p : plan) ++start[bucket_of(p) + 1];
+        std::vector<uint32_t> start((size_t)n_groups * PER_GROUP + 1, 0);
+        for (const Planned& p : plan) {
+            ++start[bucket_of(p) + 1];
+            ++n_by_t[group_of(p)];
+        }
         for (size_t b = 0; b + 1 < start.size(); ++b) start[b + 1] += start[b];
-        n_fast = start[PER_GROUP];
         for (const Planned& p : plan) items[start[bucket_of(p)]++] = p.it;
     }
 
@@ -837,7 +846,7 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     a.tmp_unit = ix->t_unit.as<uint32_t>(); a.tmp_score = ix->t_score.as<double>(); a.tmp_matched = ix->t_mat.as<uint32_t>();
     a.tmp_tie = ix->t_tie.as<uint32_t>(); a.tmp_count = ix->t_count.as<uint32_t>();
     phase_begin(ix, "score_topk");
-    launch_score(a, n_fast, ix->score_window, ix->stream);
+    launch_score(a, n_by_t.data(), ix->score_impl, ix->stream);
     phase_end(ix);
     if (n_tmp) {
         MergeArgs m{};

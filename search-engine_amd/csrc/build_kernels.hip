@@ -912,6 +912,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
             const uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
             pu[li] = unit;
             pw[li] = kept ? w : POST_HOLE;
+            // weights of 0xFFFF tenths and more do not fit the 16-bit accumulator fields of the stepwise scoring kernels
+            if (__ballot(kept & (w >= 0xFFFFu)) && lane == 0) atomicOr(err, DEV_BIG_WEIGHT);
             n_kept += (uint32_t)__popcll(km);
             n_wh += (uint32_t)__popcll(wm);
             n_kept_web += (uint32_t)__popcll(km & wm);
@@ -1011,6 +1013,7 @@ __global__ void k_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, u
         w = POST_HOLE - 1u;
     }
     post_w[i] = (uint32_t)w;
+    if (w >= 0xFFFFull) atomicOr(err, DEV_BIG_WEIGHT);
 }
 
 void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err, hipStream_t st) {

@@ -42,7 +42,8 @@ struct RowFmt {
 constexpr uint32_t POST_HOLE = 0xFFFFFFFFu;
 
 // device error bits raised by kernels
-enum : uint32_t { DEV_ERR_RANGE = 1u, DEV_ERR_ORDER = 2u, DEV_NEED_FIXUP = 4u };
+// DEV_BIG_WEIGHT: some posting weight does not fit 16 bits (weight + 1 > 0xFFFF): scoring uses the general kernel
+enum : uint32_t { DEV_ERR_RANGE = 1u, DEV_ERR_ORDER = 2u, DEV_NEED_FIXUP = 4u, DEV_BIG_WEIGHT = 8u };
 
 struct RawRows {
     const uint32_t* term;
@@ -173,7 +174,8 @@ struct ScoreArgs {
     uint32_t *tmp_unit, *tmp_matched, *tmp_tie, *tmp_count;
     double* tmp_score;
 };
-void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st);
+// n_by_t[i], i < score_fast_max_terms(): items with i + 1 lists; n_by_t[score_fast_max_terms()]: the rest
+void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, int impl, hipStream_t st);
 uint32_t score_fast_max_terms();
 struct MergeArgs {
     uint32_t n_queries, k;

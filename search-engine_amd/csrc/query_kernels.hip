@@ -35,17 +35,22 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, ui
     return ka > kb || (ka == kb && ta < tb);
 }
 
-// Candidate buffer of one wave (LDS).  Slots [0, n) are live; after cut() they are sorted best
-// first and n <= k.  offer() adds up to 64 candidates behind a cut, so CAP must be at least k + 64.
-// HAS_TIE = false: the tie-break key of every candidate equals its unit (no url ranks were given), so
-// it is not stored.
+// Candidate buffer of one wave (LDS) for k up to S = CAP - 64.  Slots [0, S) hold the best candidates
+// seen so far, sorted best first (dead slots hold the worst key); slots [S, S + 64) collect new
+// candidates.  When those 64 are full, cut() sorts them in registers (a 64-lane bitonic network of
+// lane-exchange steps) and merges them into the sorted part with one mirror stage and the
+// half-cleaner stages of a bitonic merge over [0, S): what falls out of the best S is dropped.
+// HAS_TIE = false: the tie-break key of every candidate equals its unit (no url ranks were given),
+// so it is not stored.
 template <int CAP, bool HAS_TIE = true>
 struct TopK {
+    static constexpr uint32_t S = CAP - 64;
+    static_assert(S >= 64 && (S & (S - 1)) == 0, "the sorted part is a power of two");
     uint64_t* key;
     uint32_t* unit;
     uint32_t* tie_;          // only when HAS_TIE
     unsigned char* mat;      // matched terms (at most 64)
-    uint32_t n;
+    uint32_t ns, np;         // live entries of the sorted part, entries waiting behind it
     uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
     uint32_t thr_tie;
     double thr_score;  // thr_key as a score (-inf while fewer than k candidates are held): a cheap first test
@@ -55,15 +60,22 @@ struct TopK {
         unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
         tie_ = unit + CAP;
         mat = reinterpret_cast<unsigned char*>(unit + (HAS_TIE ? 2 : 1) * CAP);
-        n = 0;
+        ns = np = 0;
         thr_key = 0;
         thr_tie = 0xFFFFFFFFu;
         thr_score = -__builtin_huge_val();
+        for (uint32_t i = lane_id(); i < S; i += 64) {
+            key[i] = 0;
+            if (HAS_TIE) tie_[i] = 0xFFFFFFFFu;
+            unit[i] = 0xFFFFFFFFu;
+            mat[i] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + (HAS_TIE ? 4 : 0) + 1) + 15) / 16 * 16; }
     __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
 
-    // one compare-exchange of the sorting network: the better entry goes to slot lo
+    // one compare-exchange of the merge network: the better entry goes to slot lo
     __device__ __forceinline__ void order(uint32_t lo, uint32_t hi) {
         const uint64_t klo = key[lo], khi = key[hi];
         const uint32_t ul = unit[lo], uh = unit[hi];
@@ -83,44 +95,57 @@ struct TopK {
         }
     }
 
-    // Wave-wide bitonic sort of all CAP slots (dead slots hold the worst key), best first.  Every
-    // comparator puts the better entry into the lower slot (a merge starts with a mirror stage
-    // instead of sorting half the blocks the other way), so the network for the next power of two
-    // sorts any CAP: comparators that reach past CAP would compare with a worst entry that stays
-    // where it is, and are skipped.
     __device__ void cut(uint32_t k) {
-        constexpr uint32_t P = CAP <= 64 ? 64 : CAP <= 128 ? 128 : CAP <= 256 ? 256 : CAP <= 512 ? 512 : CAP <= 1024 ? 1024
-                               : CAP <= 2048 ? 2048 : 4096;
-        static_assert(CAP <= 4096 && CAP % 64 == 0, "candidate buffer sizes are multiples of 64 up to 4096");
         const uint32_t lane = lane_id();
-        for (uint32_t i = n + lane; i < CAP; i += 64) {
-            key[i] = 0;
-            if (HAS_TIE) tie_[i] = 0xFFFFFFFFu;
-            unit[i] = 0xFFFFFFFFu;
-            mat[i] = 0;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t lg = 1; (1u << lg) <= P; ++lg) {
-            const uint32_t size = 1u << lg, half = size >> 1;
-#pragma unroll 1
-            for (uint32_t e = lane; e < P / 2; e += 64) {  // mirror stage
-                const uint32_t blk = (e >> (lg - 1u)) << lg, i = e & (half - 1u);
-                const uint32_t lo = blk + i, hi = blk + size - 1u - i;
-                if (hi < CAP) order(lo, hi);
+        if (np) {
+            // ---- the waiting entries, one per lane, sorted best first across the lanes
+            const bool live = lane < np;
+            uint64_t kk = live ? key[S + lane] : 0ull;
+            uint32_t uu = live ? unit[S + lane] : 0xFFFFFFFFu;
+            uint32_t tt = HAS_TIE ? (live ? tie_[S + lane] : 0xFFFFFFFFu) : uu;
+            uint32_t mm = live ? mat[S + lane] : 0u;
+            auto exchange = [&](uint32_t mask, uint32_t top) {  // partner = lane ^ mask; top = highest bit of mask
+                const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)kk, (int)mask);
+                const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(kk >> 32), (int)mask);
+                const uint32_t pu = (uint32_t)__shfl_xor((int)uu, (int)mask);
+                const uint32_t pt = HAS_TIE ? (uint32_t)__shfl_xor((int)tt, (int)mask) : pu;
+                const uint32_t pmat = (uint32_t)__shfl_xor((int)mm, (int)mask);
+                const uint64_t pk = ((uint64_t)phi << 32) | plo;
+                const bool lower = (lane & top) == 0u;
+                const bool partner_better = better(pk, pt, kk, tt), mine_better = better(kk, tt, pk, pt);
+                if (lower ? partner_better : mine_better) {  // the lower lane keeps the better entry
+                    kk = pk;
+                    uu = pu;
+                    tt = pt;
+                    mm = pmat;
+                }
+            };
+#pragma unroll
+            for (uint32_t lg = 1; lg <= 6; ++lg) {
+                exchange((1u << lg) - 1u, 1u << (lg - 1u));  // mirror stage
+#pragma unroll
+                for (uint32_t stride = 1u << (lg - 1u) >> 1; stride > 0; stride >>= 1) exchange(stride, stride);
             }
+            key[S + lane] = kk;
+            unit[S + lane] = uu;
+            if (HAS_TIE) tie_[S + lane] = tt;
+            mat[S + lane] = (unsigned char)mm;
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t stride = half >> 1; stride > 0; stride >>= 1) {
+            // ---- merge: mirror stage across the boundary, then half-cleaners over the sorted part
+            order(S - 64u + lane, S + 63u - lane);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t stride = S >> 1; stride > 0; stride >>= 1) {
 #pragma unroll 1
-                for (uint32_t e = lane; e < P / 2; e += 64) {
+                for (uint32_t e = lane; e < S / 2; e += 64) {
                     const uint32_t lo = ((e & ~(stride - 1)) << 1) | (e & (stride - 1));
-                    const uint32_t hi = lo | stride;
-                    if (hi < CAP) order(lo, hi);
+                    order(lo, lo | stride);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            ns = min(ns + np, S);
+            np = 0;
         }
-        if (n > k) n = k;
-        if (n == k && k > 0) {
+        if (ns >= k && k > 0) {
             thr_key = key[k - 1];
             thr_tie = tie(k - 1);
             thr_score = key_score(thr_key);
@@ -132,25 +157,26 @@ struct TopK {
         bool pass = has && better(ck, ct, thr_key, thr_tie);
         uint64_t pm = __ballot(pass);
         if (pm == 0) return;
-        if (n + (uint32_t)__popcll(pm) > CAP) {
+        if (np + (uint32_t)__popcll(pm) > 64u) {
             cut(k);
             pass = has && better(ck, ct, thr_key, thr_tie);
             pm = __ballot(pass);
         }
         if (pass) {
-            const uint32_t pos = n + (uint32_t)__popcll(pm & lanemask_lt());
+            const uint32_t pos = S + np + (uint32_t)__popcll(pm & lanemask_lt());
             key[pos] = ck;
             if (HAS_TIE) tie_[pos] = ct;
             unit[pos] = cu;
             mat[pos] = (unsigned char)cm;
         }
-        n += (uint32_t)__popcll(pm);
+        np += (uint32_t)__popcll(pm);
         __builtin_amdgcn_wave_barrier();
     }
 
     __device__ void write_out(uint32_t k, uint32_t* o_unit, double* o_score, uint32_t* o_mat, uint32_t* o_tie,
                               uint32_t* o_count) {
         cut(k);
+        const uint32_t n = min(ns, k);
         for (uint32_t i = lane_id(); i < k; i += 64) {
             const bool live = i < n;
             o_unit[i] = live ? unit[i] : 0xFFFFFFFFu;
@@ -266,12 +292,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
-// Fast path for queries with at most FAST_T lists.  Each list is read in chunks of 64 slots
-// aligned to 64 (one coalesced load of units, one of weights); three chunks per list sit in
-// registers and the fourth is requested the moment the first is used up, two chunks before its
-// data is needed, so a window normally touches no global memory on its critical path.  The doc
-// ids first touched in a window are appended to a dense list, so the harvest offers 64
-// candidates per step instead of scanning a sparse bitmap.
+// queries with at most FAST_T lists take the stepwise kernels below
 constexpr int FAST_T = 4;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -279,139 +300,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)b >> 32), l);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-template <int CAP, int WINSZ>
-__global__ __launch_bounds__(64) void k_score_fast(ScoreArgs a) {
-    __shared__ __align__(16) double acc[WINSZ];
-    __shared__ unsigned char cnt[WINSZ];
-    __shared__ uint32_t touched[WINSZ / 32];
-    __shared__ unsigned short olist[WINSZ];
-    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
-
-    const QItem it = a.items[blockIdx.x];
-    const uint32_t lane = lane_id();
-    const uint64_t lt = lanemask_lt();
-    const uint32_t T = it.n_terms;
-    constexpr uint32_t INF = 0xFFFFFFFFu;
-
-    uint32_t my_cur = 0, my_end = 0;
-    double my_idf = 0.0;
-    if (lane < T) {
-        const uint32_t term = a.q_terms[it.term_off + lane];
-        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
-        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
-        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
-        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
-    }
-    // per list: slot index of the current chunk's lane 0, first unconsumed lane of that chunk, end
-    // of the list, and three chunks of units / weights (slots outside [cursor, end) read as INF)
-    uint32_t pos[FAST_T], off[FAST_T], end[FAST_T];
-    uint32_t u0[FAST_T], u1[FAST_T], u2[FAST_T], w0[FAST_T], w1[FAST_T], w2[FAST_T];
-    double idf[FAST_T];
-    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& u, uint32_t& w) {
-        const uint32_t i = p + lane;
-        const bool ok = i >= lo && i < end[t];
-        u = ok ? a.post_unit[i] : INF;
-        w = ok ? a.post_w[i] : POST_HOLE;
-    };
-#pragma unroll
-    for (int t = 0; t < FAST_T; ++t) {
-        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
-        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
-        idf[t] = readlane_f64(my_idf, t);
-        pos[t] = cur & ~63u;
-        off[t] = cur & 63u;
-        if (cur >= end[t]) {  // empty list (or t >= T): nothing to read
-            pos[t] = 0;
-            off[t] = 0;
-            end[t] = 0;
-        }
-        load_chunk(t, pos[t], cur, u0[t], w0[t]);
-        load_chunk(t, pos[t] + 64u, cur, u1[t], w1[t]);
-        load_chunk(t, pos[t] + 128u, cur, u2[t], w2[t]);
-    }
-    if (lane < WINSZ / 32) touched[lane] = 0;
-    TopK<CAP> tk;
-    tk.init(topk_mem);
-    uint32_t n_o = 0;
-    __builtin_amdgcn_wave_barrier();
-
-    while (true) {
-        // window start: the smallest unit any list still has to deliver
-        uint32_t nxt = INF;
-#pragma unroll
-        for (int t = 0; t < FAST_T; ++t)
-            if ((uint32_t)t < T) nxt = min(nxt, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], (int)off[t]));
-        if (nxt == INF) break;
-        const uint32_t base = nxt & ~31u;
-        const uint64_t wend = (uint64_t)base + WINSZ;
-
-#pragma unroll
-        for (int t = 0; t < FAST_T; ++t) {
-            if ((uint32_t)t >= T) break;
-            while (true) {
-                // the unconsumed slots of the current chunk that fall into the window
-                const bool in = lane >= off[t] && u0[t] != INF && (uint64_t)u0[t] < wend;
-                const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-                bool first = false;
-                uint32_t idx = 0;
-                if (in && w0[t] != POST_HOLE) {  // a hole only moves the cursor
-                    const double v = __dmul_rn(idf[t], (double)w0[t]);
-                    idx = u0[t] - base;
-                    const uint32_t bit = 1u << (idx & 31u);
-                    const uint32_t old = atomicOr(&touched[idx >> 5], bit);
-                    first = !(old & bit);
-                    if (first) {
-                        acc[idx] = v;
-                        cnt[idx] = 1;
-                    } else {
-                        acc[idx] = __dadd_rn(acc[idx], v);
-                        cnt[idx] = (unsigned char)(cnt[idx] + 1);
-                    }
-                }
-                const uint64_t om = __ballot(first);
-                if (first) olist[n_o + (uint32_t)__popcll(om & lt)] = (unsigned short)idx;
-                n_o += (uint32_t)__popcll(om);
-                off[t] += n_in;
-                if (off[t] < 64u) break;
-                // chunk used up: the next two are in registers already, request the one after them
-                u0[t] = u1[t]; w0[t] = w1[t];
-                u1[t] = u2[t]; w1[t] = w2[t];
-                pos[t] += 64u;
-                off[t] = 0;
-                load_chunk(t, pos[t] + 128u, 0u, u2[t], w2[t]);
-                __builtin_amdgcn_wave_barrier();
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-
-        // harvest: every doc id touched in this window, 64 per step
-        for (uint32_t o0 = 0; o0 < n_o; o0 += 64) {
-            const bool has = o0 + lane < n_o;
-            double s = 0.0;
-            uint32_t m = 0, unit = 0, tie = 0;
-            if (has) {
-                const uint32_t idx = olist[o0 + lane];
-                s = acc[idx];
-                m = cnt[idx];
-                touched[idx >> 5] = 0;
-                unit = base + idx;
-                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
-            }
-            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
-        }
-        n_o = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    const size_t o = (size_t)it.out_slot * a.k;
-    if (it.direct)
-        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
-                     a.out_count + it.out_slot);
-    else
-        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
 // Fast path in posting space.  Instead of windows of unit ids (whose lanes are mostly idle when the
@@ -573,6 +461,296 @@ __global__ __launch_bounds__(64, hash_waves_per_simd(CAP)) void k_score_hash(Sco
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
+// ------------------------------------------------------------------------------------------
+// Stepwise scoring (the default for queries of at most FAST_T lists).
+//
+// As above a step takes, from every list, all slots up to the frontier F.  What differs:
+//  * The accumulators hold the integer weights, one 16-bit field per list (weight + 1, 0 = no
+//    posting).  A list only ever writes its own field, so adding a posting is a plain 2-byte store
+//    (no read-modify-write), the number of matching lists is the number of non-zero fields, and the
+//    score is formed at harvest as the same double sum in query-term order as on every other path.
+//  * Units wait in the table until 64 of them can be harvested together.  No entry is looked up after
+//    the step that created it, so removing entries at step ends keeps every probe sequence of the
+//    running step intact.
+//  * A slot that has been used is overwritten with INF in its register, so "still to do" needs no
+//    per-list cursor: a list's part of a step is simply `unit <= F`.
+//  * For k <= 64 the best k sit in registers, one per lane, sorted; a candidate is placed with one
+//    ballot and one lane shift, and the k-th best is exact at every moment.
+//
+// Tried and dropped: dropping postings that cannot reach the current k-th best score (a per-list
+// minimum weight from the other lists' largest in-step weights), with and without a first pass over
+// the short lists to learn the threshold early.  Exact, but half of the postings of the benchmark
+// batch belong to queries with two or three long lists, whose 64-slot chunks nearly always hold a
+// title hit: the bound stays loose, a third of the postings survive, and the bookkeeping costs more
+// than the skipped insertions save (3.97 ms per batch against 3.66 without).
+
+__device__ __forceinline__ uint32_t lane_from_below(uint32_t x) {  // lane i <- lane i-1, lane 0 keeps its own
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+
+// The best k <= 64 candidates in registers: lane i holds the i-th best (empty lanes hold the worst key).
+template <bool HAS_TIE>
+struct RegTopK {
+    uint64_t key;
+    uint32_t unit, tie_, mat;
+    uint32_t n;
+    uint64_t thr_key;
+    uint32_t thr_tie;
+    double thr_score;
+    static constexpr size_t bytes() { return 16; }
+    __device__ void init(unsigned char*) {
+        key = 0;
+        unit = 0xFFFFFFFFu;
+        tie_ = 0xFFFFFFFFu;
+        mat = 0;
+        n = 0;
+        thr_key = 0;
+        thr_tie = 0xFFFFFFFFu;
+        thr_score = -__builtin_huge_val();
+    }
+    __device__ __forceinline__ uint32_t tie() const { return HAS_TIE ? tie_ : unit; }
+    // every lane may offer one candidate; wave-uniform control flow
+    __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
+        uint64_t pm = __ballot(has && better(ck, ct, thr_key, thr_tie));
+        const uint32_t lane = lane_id();
+        while (pm) {
+            const int l = __ffsll((unsigned long long)pm) - 1;
+            pm &= pm - 1ull;
+            const uint64_t k1 = readlane_u64(ck, l);
+            const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)ct, l);
+            const uint32_t u1 = (uint32_t)__builtin_amdgcn_readlane((int)cu, l);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_readlane((int)cm, l);
+            if (!better(k1, t1, thr_key, thr_tie)) continue;  // the k-th best may have risen meanwhile
+            // lanes whose entry ranks behind the candidate: a suffix of the wave, never empty here
+            const uint64_t b = __ballot(better(k1, t1, key, tie()));
+            const uint32_t pos = (uint32_t)__ffsll((unsigned long long)b) - 1u;
+            if (pos >= k) continue;
+            const uint32_t klo = lane_from_below((uint32_t)key), khi = lane_from_below((uint32_t)(key >> 32));
+            const uint32_t us = lane_from_below(unit), ms = lane_from_below(mat);
+            const uint32_t ts = HAS_TIE ? lane_from_below(tie_) : 0u;
+            if (lane > pos) {
+                key = ((uint64_t)khi << 32) | klo;
+                unit = us;
+                mat = ms;
+                if (HAS_TIE) tie_ = ts;
+            } else if (lane == pos) {
+                key = k1;
+                unit = u1;
+                mat = m1;
+                if (HAS_TIE) tie_ = t1;
+            }
+            if (n < k) ++n;
+            if (n == k) {
+                thr_key = readlane_u64(key, (int)k - 1);
+                thr_tie = (uint32_t)__builtin_amdgcn_readlane((int)tie(), (int)k - 1);
+                thr_score = key_score(thr_key);
+            }
+        }
+    }
+    __device__ void write_out(uint32_t k, uint32_t* o_unit, double* o_score, uint32_t* o_mat, uint32_t* o_tie,
+                              uint32_t* o_count) {
+        const uint32_t i = lane_id();
+        if (i < k) {
+            const bool live = i < n;
+            o_unit[i] = live ? unit : 0xFFFFFFFFu;
+            o_score[i] = live ? key_score(key) : 0.0;
+            o_mat[i] = live ? mat : 0u;
+            if (o_tie) o_tie[i] = live ? tie() : 0xFFFFFFFFu;
+        }
+        if (i == 0) *o_count = n;
+    }
+};
+
+constexpr int STEP_SLOTS = 512;
+#ifndef SEBM25_STEP_DEPTH
+#define SEBM25_STEP_DEPTH 3
+#endif
+constexpr int STEP_DEPTH = SEBM25_STEP_DEPTH;  // chunks of a list held in registers
+
+#ifdef SEBM25_EXP_STATS  // experiment builds only: steps, insert passes, postings inserted, harvest rounds, offers, items
+__device__ unsigned long long g_step_stats[8];
+#endif
+
+__device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) {
+    static_assert(T >= 1 && T <= FAST_T, "one 16-bit accumulator field per list");
+    __shared__ uint32_t tag[STEP_SLOTS];
+    __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * 4];  // per slot and list: weight in tenths + 1
+    __shared__ unsigned short used[64 * T + 64];
+    __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
+
+    const QItem it = a.items[blockIdx.x];
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+
+    uint32_t my_cur = 0, my_end = 0;
+    double my_idf = 0.0;
+    if (lane < (uint32_t)T) {
+        const uint32_t term = a.q_terms[it.term_off + lane];
+        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
+        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
+    }
+    // per list: slot index of the current chunk's lane 0, end of the list, the unit in the current
+    // chunk's last lane, and STEP_DEPTH aligned chunks of units / weights.  A slot outside
+    // [cursor, end) and a slot already used read as INF.
+    uint32_t pos[T], end[T], last[T];
+    uint32_t u[T][STEP_DEPTH], w[T][STEP_DEPTH];
+    double idf[T];
+    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& uu, uint32_t& ww) {
+        const uint32_t i = p + lane;
+        const bool ok = i >= lo && i < end[t];
+        uu = ok ? a.post_unit[i] : INF;
+        ww = ok ? a.post_w[i] : POST_HOLE;
+    };
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
+        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
+        idf[t] = readlane_f64(my_idf, t);
+        pos[t] = cur & ~63u;
+        if (cur >= end[t]) {  // empty list: nothing to read
+            pos[t] = 0;
+            end[t] = 0;
+        }
+#pragma unroll
+        for (int d = 0; d < STEP_DEPTH; ++d) load_chunk(t, pos[t] + 64u * (uint32_t)d, cur, u[t][d], w[t][d]);
+    }
+    for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS; x += 64) {
+        tag[x] = HASH_EMPTY;
+        *reinterpret_cast<uint64_t*>(&wfield[x * 4u]) = 0ull;
+    }
+    TK tk;
+    tk.init(topk_mem);
+    uint32_t n_used = 0;
+#ifdef SEBM25_EXP_STATS
+    uint32_t st_steps = 0, st_ins = 0, st_rounds = 0, st_offers = 0, st_passes = 0;
+#endif
+#pragma unroll
+    for (int t = 0; t < T; ++t) last[t] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][0], 63);
+    __builtin_amdgcn_wave_barrier();
+
+    while (true) {
+        uint32_t F = last[0];
+#pragma unroll
+        for (int t = 1; t < T; ++t) F = min(F, last[t]);
+        F = sfirst(F);
+        const bool final_step = F == INF;  // every list is in its last chunk: take what is left
+        const uint32_t Fc = min(F, INF - 1u);
+
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool in = u[t][0] <= Fc;
+            const bool s = in && w[t][0] != POST_HOLE;  // a hole only leaves its chunk
+            const uint64_t sm = __ballot(s);
+#ifdef SEBM25_EXP_STATS
+            st_ins += (uint32_t)__popcll(sm);
+            st_passes += sm ? 1u : 0u;
+            if (t == 0) ++st_steps;
+#endif
+            if (sm) {
+                bool fresh = false;
+                uint32_t h = 0;
+                if (s) {
+                    const uint32_t un = u[t][0];
+                    h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
+                    while (true) {
+                        const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, un);
+                        if (old == HASH_EMPTY) {
+                            fresh = true;
+                            break;
+                        }
+                        if (old == un) break;
+                        h = (h + 1u) & (STEP_SLOTS - 1u);
+                    }
+                    wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][0] + 1u);
+                }
+                const uint64_t fm = __ballot(fresh);
+                if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
+                n_used += (uint32_t)__popcll(fm);
+                __builtin_amdgcn_wave_barrier();
+            }
+            // used slots leave their chunk; a chunk whose last slot is used is replaced by the next one
+            if (last[t] <= Fc) {
+#pragma unroll
+                for (int d = 0; d + 1 < STEP_DEPTH; ++d) {
+                    u[t][d] = u[t][d + 1];
+                    w[t][d] = w[t][d + 1];
+                }
+                pos[t] += 64u;
+                load_chunk(t, pos[t] + 64u * (STEP_DEPTH - 1), 0u, u[t][STEP_DEPTH - 1], w[t][STEP_DEPTH - 1]);
+                last[t] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][0], 63);
+            } else {
+                u[t][0] = in ? INF : u[t][0];
+            }
+        }
+
+        // harvest 64 units at a time from the back of the list of used slots
+        while (n_used >= 64u || (final_step && n_used)) {
+            const uint32_t take = min(n_used, 64u);
+            n_used -= take;
+            const bool has = lane < take;
+            double s = 0.0;
+            uint32_t m = 0, unit = 0;
+            if (has) {
+                const uint32_t h = used[n_used + lane];
+                unit = tag[h];
+                const uint64_t f = *reinterpret_cast<const uint64_t*>(&wfield[h * 4u]);
+                tag[h] = HASH_EMPTY;
+                *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = 0ull;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const uint32_t ft = (uint32_t)(f >> (16 * t)) & 0xFFFFu;
+                    if (ft) {
+                        const double v = __dmul_rn(idf[t], (double)(ft - 1u));
+                        s = m ? __dadd_rn(s, v) : v;
+                        ++m;
+                    }
+                }
+            }
+            // most units cannot enter the top k any more: test the score alone before anything else
+            const bool may = has && s >= tk.thr_score;
+#ifdef SEBM25_EXP_STATS
+            ++st_rounds;
+            st_offers += (uint32_t)__popcll(__ballot(may));
+#endif
+            if (__ballot(may)) {
+                uint32_t tie = 0;
+                if (may) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
+                tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (final_step) break;
+    }
+#ifdef SEBM25_EXP_STATS
+    if (lane == 0) {
+        atomicAdd(&g_step_stats[0], (unsigned long long)st_steps);
+        atomicAdd(&g_step_stats[1], (unsigned long long)st_passes);
+        atomicAdd(&g_step_stats[2], (unsigned long long)st_ins);
+        atomicAdd(&g_step_stats[3], (unsigned long long)st_rounds);
+        atomicAdd(&g_step_stats[4], (unsigned long long)st_offers);
+        atomicAdd(&g_step_stats[5], 1ull);
+    }
+#endif
+
+    const size_t o = (size_t)it.out_slot * a.k;
+    if (it.direct)
+        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                     a.out_count + it.out_slot);
+    else
+        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+}
+
 // one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
 template <int CAP>
 __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
@@ -601,47 +779,62 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 
 }  // namespace
 
-// items [0, n_fast) have at most FAST_T lists, the rest use the general kernel
-void launch_score(const ScoreArgs& a, uint32_t n_fast, int window, hipStream_t st) {
-    if (n_fast && window == 0) {  // posting-space steps with hashed accumulators
-        dim3 grid(n_fast), block(64);
-        if (a.url_rank) {
-            if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, true>), grid, block, 0, st, a);
-            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_hash<2112, true>), grid, block, 0, st, a);
-        } else {
-            if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, false>), grid, block, 0, st, a);
-            else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_hash<2112, false>), grid, block, 0, st, a);
-        }
-    } else if (n_fast) {
-        dim3 grid(n_fast), block(64);
-        if (a.k <= 64) {
-            if (window <= 512) hipLaunchKernelGGL((k_score_fast<128, 512>), grid, block, 0, st, a);
-            else if (window <= 1024) hipLaunchKernelGGL((k_score_fast<128, 1024>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_fast<128, 2048>), grid, block, 0, st, a);
-        } else if (a.k <= 256) {
-            if (window <= 1024) hipLaunchKernelGGL((k_score_fast<320, 1024>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_score_fast<320, 2048>), grid, block, 0, st, a);
-        } else {
-            hipLaunchKernelGGL((k_score_fast<2112, 1024>), grid, block, 0, st, a);
-        }
-    }
-    if (a.n_items > n_fast) {
+// Items are grouped by their number of lists: n_by_t[i] items with i + 1 lists for i < FAST_T (stepwise
+// kernels, one instantiation per list count), then n_by_t[FAST_T] items for the general kernel.
+// impl 1 selects the older hashed-accumulator kernel for the first groups (kept for comparison).
+template <int T, bool HAS_RANK>
+static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
+    dim3 grid(b.n_items), block(64);
+    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, 5>), grid, block, 0, st, b);
+    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, 3>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1>), grid, block, 0, st, b);
+}
+template <int T>
+static void launch_step(const ScoreArgs& b, hipStream_t st) {
+    if (b.url_rank) launch_step_t<T, true>(b, st); else launch_step_t<T, false>(b, st);
+}
+
+void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, int impl, hipStream_t st) {
+    uint32_t first = 0;
+    for (int g = 0; g <= FAST_T; ++g) {
+        const uint32_t n = n_by_t[g];
+        if (n == 0) continue;
         ScoreArgs b = a;
-        b.items = a.items + n_fast;
-        b.n_items = a.n_items - n_fast;
-        dim3 grid(b.n_items), block(64);
-        if (a.k <= 64)
-            hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, b);
-        else if (a.k <= 256)
-            hipLaunchKernelGGL(k_score<320>, grid, block, 0, st, b);
-        else
-            hipLaunchKernelGGL(k_score<2112>, grid, block, 0, st, b);
+        b.items = a.items + first;
+        b.n_items = n;
+        first += n;
+        dim3 grid(n), block(64);
+        if (g == FAST_T) {
+            if (a.k <= 64) hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, b);
+            else if (a.k <= 256) hipLaunchKernelGGL(k_score<320>, grid, block, 0, st, b);
+            else hipLaunchKernelGGL(k_score<2112>, grid, block, 0, st, b);
+        } else if (impl == 1) {
+            if (a.url_rank) {
+                if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, true>), grid, block, 0, st, b);
+                else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, true>), grid, block, 0, st, b);
+                else hipLaunchKernelGGL((k_score_hash<2112, true>), grid, block, 0, st, b);
+            } else {
+                if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, false>), grid, block, 0, st, b);
+                else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, false>), grid, block, 0, st, b);
+                else hipLaunchKernelGGL((k_score_hash<2112, false>), grid, block, 0, st, b);
+            }
+        } else if (g == 0) launch_step<1>(b, st);
+        else if (g == 1) launch_step<2>(b, st);
+        else if (g == 2) launch_step<3>(b, st);
+        else launch_step<4>(b, st);
     }
 }
 
 uint32_t score_fast_max_terms() { return FAST_T; }
+
+#ifdef SEBM25_EXP_STATS
+extern "C" int sebm25_exp_stats(unsigned long long* out8, int reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_step_stats), sizeof(z)) != hipSuccess) return 1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_step_stats), z, sizeof(z)) != hipSuccess) return 1;
+    return 0;
+}
+#endif
 
 void launch_merge(const MergeArgs& a, hipStream_t st) {
     if (a.n_queries == 0) return;
