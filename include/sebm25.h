@@ -208,6 +208,25 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
                   uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count);
 
 /*
+ * sebm25_search for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, results
+ * and ordering as sebm25_search, but the call allocates nothing on the device or the host: the work
+ * items, the deduplicated query terms and the temporary result lists of queries that are split by
+ * unit range live in one fixed device array of about 2.8 MB per GPU (held from sebm25_create of the
+ * first handle on that GPU until the process ends), and the host-side plan in pinned storage of the
+ * handle.  Limits: n_queries <= 1024, k <= 256, at most 4096 distinct matching query terms per call
+ * (SEBM25_E_RANGE beyond them); all output arrays must be device memory (out_tie may be NULL).  A
+ * batch whose split queries would need more than 131072 temporary entries (lists x k) or more than
+ * 4096 work items is scored without splitting, which changes the speed and never the result.  All
+ * calls on one GPU share that GPU's array: within a process they are serialised by the library;
+ * calls from different handles must not be relied upon to overlap, and nothing in the array has to
+ * be cleared between calls (every entry read by a call is written by that call first).
+ */
+int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets,
+                          uint32_t n_queries, uint32_t k, uint32_t* out_unit, double* out_score,
+                          uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count);
+
+/*
  * Merges n_lists per-shard result sets (the layout sebm25_search writes, concatenated list by
  * list: in_x[(l * n_queries + q) * k + i], in_count[l * n_queries + q]) into one top-k per
  * query with the same ordering.  Device or host pointers.  The reference's counterpart is the

@@ -25,6 +25,13 @@ struct H2DJob {
     size_t bytes;
 };
 
+struct SearchPlanVecs {
+    std::vector<uint32_t> flat, q_toff, q_nt, q_ns, first, nlists, bucket;
+    std::vector<uint64_t> q_len, item_len;
+    std::vector<QItem> items, unsorted;
+};
+struct NaHost;
+
 struct sebm25_index {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -57,6 +64,8 @@ struct sebm25_index {
 
     std::vector<uint32_t> h_row_ptr, h_news_ptr;
     bool host_ptrs_valid = false;
+    SearchPlanVecs plan_vecs;    // host plan storage of sebm25_search, kept between calls
+    NaHost* na_host = nullptr;   // host plan storage of sebm25_search_noalloc (pinned, fixed size)
 
     // search scratch
     DevBuf q_items, q_terms, q_first, q_n;
@@ -84,6 +93,65 @@ int fail(sebm25_index* ix, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e__));                          \
         }                                                                                             \
     } while (0)
+
+}  // namespace
+
+// ---- the entry point that allocates nothing ------------------------------------------------
+// Everything sebm25_search keeps in grow-on-demand device buffers (work items, deduped terms, the
+// temporary result lists of split queries) lives here in one file-scope device array of fixed size.
+// Each GPU holds its own copy at its own address: sebm25_create looks the address up once per
+// device (hipGetSymbolAddress with that device current) and host code only ever uses that address.
+namespace {
+constexpr uint32_t PLAN_SUB = 16, PLAN_PER_GROUP = 65 * PLAN_SUB;  // counting-sort buckets of the query planner
+constexpr uint32_t NA_MAX_QUERIES = 1024, NA_MAX_TERMS = 4096, NA_MAX_ITEMS = 4096, NA_MAX_K = 256;
+constexpr uint32_t NA_TMP_ENTRIES = 131072;  // temporary lists x k
+constexpr size_t na_align(size_t x) { return (x + 255) / 256 * 256; }
+constexpr size_t NA_OFF_ITEMS = 0;
+constexpr size_t NA_OFF_TERMS = NA_OFF_ITEMS + na_align((size_t)NA_MAX_ITEMS * sizeof(QItem));
+constexpr size_t NA_OFF_FIRST = NA_OFF_TERMS + na_align((size_t)NA_MAX_TERMS * 4);
+constexpr size_t NA_OFF_NLISTS = NA_OFF_FIRST + na_align((size_t)NA_MAX_QUERIES * 4);
+constexpr size_t NA_OFF_T_UNIT = NA_OFF_NLISTS + na_align((size_t)NA_MAX_QUERIES * 4);
+constexpr size_t NA_OFF_T_SCORE = NA_OFF_T_UNIT + na_align((size_t)NA_TMP_ENTRIES * 4);
+constexpr size_t NA_OFF_T_MAT = NA_OFF_T_SCORE + na_align((size_t)NA_TMP_ENTRIES * 8);
+constexpr size_t NA_OFF_T_TIE = NA_OFF_T_MAT + na_align((size_t)NA_TMP_ENTRIES * 4);
+constexpr size_t NA_OFF_T_COUNT = NA_OFF_T_TIE + na_align((size_t)NA_TMP_ENTRIES * 4);
+constexpr size_t NA_SCRATCH_BYTES = NA_OFF_T_COUNT + na_align((size_t)NA_MAX_ITEMS * 4);  // about 2.8 MB
+constexpr int NA_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+
+namespace {
+std::mutex g_na_mu;
+unsigned char* g_na_ptr[NA_MAX_DEVICES];   // device address of `scratch` on each GPU (0: not looked up yet)
+std::mutex g_na_device_mu[NA_MAX_DEVICES];  // calls on one GPU share its array: one at a time within this process
+
+}  // namespace
+// host-side plan storage of the no-alloc entry point, allocated once per handle by sebm25_create
+struct NaHost {
+    uint32_t flat[NA_MAX_TERMS];
+    uint32_t q_toff[NA_MAX_QUERIES], q_nt[NA_MAX_QUERIES], q_ns[NA_MAX_QUERIES], first[NA_MAX_QUERIES], nlists[NA_MAX_QUERIES];
+    uint64_t q_len[NA_MAX_QUERIES];
+    QItem items[NA_MAX_ITEMS], unsorted[NA_MAX_ITEMS];
+    uint64_t item_len[NA_MAX_ITEMS];
+    uint32_t bucket[(SCORE_FAST_T + 1) * PLAN_PER_GROUP + 1];
+};
+namespace {
+
+// once per device, with that device current
+int na_setup_device(sebm25_index* ix, int device) {
+    if (device < 0 || device >= NA_MAX_DEVICES) return SEBM25_OK;  // no-alloc entry unavailable there; reported at call time
+    std::lock_guard<std::mutex> lk(g_na_mu);
+    if (g_na_ptr[device]) return SEBM25_OK;
+    void* p = nullptr;
+    HIP_TRY(ix, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_na_ptr[device] = static_cast<unsigned char*>(p);
+    return SEBM25_OK;
+}
+}  // namespace
+
+
+namespace {
 
 bool is_device_ptr(const void* p) {
     if (!p) return false;
@@ -267,6 +335,8 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
 
     ix->built = ix->finalized = false;
     ix->host_ptrs_valid = false;
+    ix->h_row_ptr.resize((size_t)in->n_terms + 1);  // filled by the first search; sized here so that a search never allocates them
+    ix->h_news_ptr.resize(in->n_terms);
     const uint64_t R = in->n_rows;
     const uint32_t V = in->n_terms;
     RowFmt fmt;
@@ -452,6 +522,22 @@ int sebm25_create(int device, sebm25_index** out) {
     ix->device = device;
     if (const char* e = getenv("SEBM25_SCORE_IMPL")) ix->score_impl = strcmp(e, "hash") == 0 ? 1 : 0;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
+    {
+        // set-up of sebm25_search_noalloc: this GPU's address of the fixed device array and the pinned host plan storage
+        DeviceGuard g(device);
+        int rc = na_setup_device(ix, device);
+        void* hp = nullptr;
+        if (rc == SEBM25_OK && hipHostMalloc(&hp, sizeof(NaHost), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            hp = nullptr;  // the entry point reports it; everything else works without
+        }
+        ix->na_host = static_cast<NaHost*>(hp);
+        if (rc) {
+            g_thread_err = ix->err;
+            delete ix;
+            return rc;
+        }
+    }
     *out = ix;
     return SEBM25_OK;
 }
@@ -470,6 +556,7 @@ void sebm25_destroy(sebm25_index* ix) {
                          &ix->m_in[3], &ix->m_in[4], &ix->gen_rows, &ix->gen_cdf};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ix->timer.ev) (void)hipEventDestroy(e);
+        if (ix->na_host) (void)hipHostFree(ix->na_host);
     }
     delete ix;
 }
@@ -681,151 +768,154 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
 
 // ---------------------------------------------------------------------------- search -------
 
-int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
-                  uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie,
-                  uint32_t* out_count) {
-    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search: handle is NULL");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    DeviceGuard g(ix->device);
-    if (!ix->built || !ix->finalized) return fail(ix, SEBM25_E_STATE, "search: index is not built and finalized");
-    if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
-        return fail(ix, SEBM25_E_INVALID, "search: source must be 1 (web) or 2 (news)");
-    if (k == 0 || k > MAX_K) return fail(ix, SEBM25_E_RANGE, "search: k must be in 1..2048");
-    if (n_queries == 0) return SEBM25_OK;
-    if (!q_offsets || !out_unit || !out_score || !out_matched || !out_count)
-        return fail(ix, SEBM25_E_INVALID, "search: NULL argument");
-    if (is_device_ptr(q_offsets) || is_device_ptr(q_terms))
-        return fail(ix, SEBM25_E_INVALID, "search: query arrays must be host memory");
-    if (q_offsets[n_queries] && !q_terms) return fail(ix, SEBM25_E_INVALID, "search: q_terms is NULL");
-    int rc = refresh_host_ptrs(ix);
-    if (rc) return rc;
-    phases_reset(ix);
+}  // extern "C"
 
-    const bool news = source == (int)SEBM25_SRC_NEWS;
+namespace {
+
+// Query planning shared by sebm25_search (storage grown on demand) and sebm25_search_noalloc
+// (storage fixed at set-up).  Pass 1 dedupes the terms of every query and decides into how many
+// unit ranges a long query is cut; pass 2 emits the work items grouped by their number of lists,
+// each group longest first.
+struct PlanStore {
+    uint32_t* flat;      // [flat_cap] deduped, matching terms of all queries
+    size_t flat_cap;
+    uint32_t *q_toff, *q_nt, *q_ns;  // [n_queries] offset into flat, number of terms, number of unit ranges
+    uint64_t* q_len;                 // [n_queries] postings of the query
+    uint32_t *first, *nlists;        // [n_queries] temporary lists of a split query (nlists 0: not split)
+    QItem* items;                    // [item_cap] sorted work items (pass 2)
+    uint64_t* item_len;              // [item_cap] scratch of pass 2
+    QItem* unsorted;                 // [item_cap] scratch of pass 2
+    size_t item_cap;
+    uint32_t* bucket;                // [plan_buckets() + 1] counting-sort scratch
+};
+struct PlanInfo {
+    uint32_t n_flat = 0, n_items = 0, n_tmp = 0;
+    uint32_t n_by_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+size_t plan_buckets() { return (size_t)(score_fast_max_terms() + 1) * PLAN_PER_GROUP; }
+
+// max_tmp_entries: capacity of the temporary slice lists in entries (lists x k); a plan that would
+// need more is made without splitting.  Returns 0 or an error code (message set).
+int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
+               uint32_t k, PlanStore& st, PlanInfo& info, uint64_t max_tmp_entries) {
     const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
     const std::vector<uint32_t>&rp = ix->h_row_ptr, &np = ix->h_news_ptr;
     auto list_len = [&](uint32_t t) -> uint64_t { return news ? rp[t + 1] - np[t] : np[t] - rp[t]; };
-
-    // ---- plan: distinct valid terms per query, then split long queries by unit range
-    std::vector<uint32_t> flat;          // deduped terms of all queries
-    std::vector<uint32_t> q_toff(n_queries), q_nt(n_queries);
-    std::vector<uint64_t> q_len(n_queries);
-    flat.reserve(q_offsets[n_queries]);
+    size_t nf = 0;
     uint64_t total_len = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
         if (q_offsets[q + 1] < q_offsets[q]) return fail(ix, SEBM25_E_INVALID, "search: q_offsets must be non-decreasing");
-        const size_t start = flat.size();
+        const size_t start = nf;
         uint64_t len = 0;
         for (uint64_t j = q_offsets[q]; j < q_offsets[q + 1]; ++j) {
             const uint32_t t = q_terms[j];
             if (t >= ix->V || list_len(t) == 0) continue;  // matches no row
             bool dup = false;
-            for (size_t x = start; x < flat.size(); ++x) dup |= flat[x] == t;
+            for (size_t x = start; x < nf; ++x) dup |= st.flat[x] == t;
             if (dup) continue;  // `= ANY($1)`: a repeated term selects its rows once
-            flat.push_back(t);
+            if (nf >= st.flat_cap) return fail(ix, SEBM25_E_RANGE, "search: too many query terms for the plan storage");
+            st.flat[nf++] = t;
             len += list_len(t);
         }
-        if (flat.size() - start > MAX_QUERY_TERMS)
+        if (nf - start > MAX_QUERY_TERMS)
             return fail(ix, SEBM25_E_RANGE, "search: more than 64 distinct matching terms in one query");
-        q_toff[q] = (uint32_t)start;
-        q_nt[q] = (uint32_t)(flat.size() - start);
-        q_len[q] = len;
+        st.q_toff[q] = (uint32_t)start;
+        st.q_nt[q] = (uint32_t)(nf - start);
+        st.q_len[q] = len;
         total_len += len;
     }
+    info.n_flat = (uint32_t)nf;
     // postings per work item: enough items to fill the GPU, few enough that per-item set-up
     // (binary searches, final cut) stays small next to the streaming
     uint64_t slice = std::min<uint64_t>(std::max<uint64_t>(total_len / 8192, 8192), 131072);
     slice = std::max<uint64_t>(slice, (uint64_t)k * 32);
-    struct Planned { QItem it; uint64_t len; };
-    std::vector<Planned> plan;
-    plan.reserve(n_queries);
-    std::vector<uint32_t> first(n_queries, 0), nlists(n_queries, 0);
-    uint32_t n_tmp = 0;
-    for (uint32_t q = 0; q < n_queries; ++q) {
-        uint32_t ns = (uint32_t)std::min<uint64_t>((q_len[q] + slice - 1) / slice, 64);
-        ns = std::max(1u, std::min(ns, std::max(1u, n_units / 4096u)));
-        if (ns > 1) {
-            first[q] = n_tmp;
-            nlists[q] = ns;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint64_t n_items = 0, n_tmp = 0;
+        for (uint32_t q = 0; q < n_queries; ++q) {
+            uint32_t ns = 1;
+            if (attempt == 0) {
+                ns = (uint32_t)std::min<uint64_t>((st.q_len[q] + slice - 1) / slice, 64);
+                ns = std::max(1u, std::min(ns, std::max(1u, n_units / 4096u)));
+            }
+            st.q_ns[q] = ns;
+            n_items += ns;
+            if (ns > 1) n_tmp += ns;
         }
-        for (uint32_t s = 0; s < ns; ++s) {
+        info.n_items = (uint32_t)n_items;
+        info.n_tmp = (uint32_t)n_tmp;
+        if (n_tmp * k <= max_tmp_entries) break;  // else: plan again without splitting
+    }
+    return SEBM25_OK;
+}
+
+int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, PlanInfo& info) {
+    if (info.n_items > st.item_cap) return fail(ix, SEBM25_E_RANGE, "search: too many work items for the plan storage");
+    const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
+    const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
+    const uint32_t n_groups = score_fast_max_terms() + 1;
+    uint32_t n = 0, n_tmp = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        const uint32_t ns = st.q_ns[q];
+        st.first[q] = ns > 1 ? n_tmp : 0u;
+        st.nlists[q] = ns > 1 ? ns : 0u;
+        for (uint32_t sl = 0; sl < ns; ++sl) {
             QItem it{};
             it.q = q;
-            it.term_off = q_toff[q];
-            it.n_terms = q_nt[q];
-            it.unit_lo = (uint32_t)((uint64_t)n_units * s / ns);
-            it.unit_hi = s + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (s + 1) / ns);
+            it.term_off = st.q_toff[q];
+            it.n_terms = st.q_nt[q];
+            it.unit_lo = (uint32_t)((uint64_t)n_units * sl / ns);
+            it.unit_hi = sl + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (sl + 1) / ns);
             it.direct = ns == 1;
             it.out_slot = ns == 1 ? q : n_tmp++;
-            plan.push_back({it, q_len[q] / ns});
+            st.unsorted[n] = it;
+            st.item_len[n] = st.q_len[q] / ns;
+            ++n;
         }
     }
-    // items grouped by their number of lists (1 .. fast_t, then everything longer), each group longest
-    // first so the tail of a launch is short work; a counting sort on the length's bit count and its
-    // next four bits (order within 6 %), linear in the item count
-    const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
-    std::vector<QItem> items(plan.size());
-    std::vector<uint32_t> n_by_t(score_fast_max_terms() + 1, 0);
-    {
-        constexpr uint32_t SUB = 16, PER_GROUP = 65 * SUB;
-        const uint32_t n_groups = score_fast_max_terms() + 1;
-        // a query without a matching term still needs its (empty) result row written: the general kernel does that
-        auto group_of = [&](const Planned& p) -> uint32_t {
-            return p.it.n_terms >= 1u && p.it.n_terms <= fast_t ? p.it.n_terms - 1u : n_groups - 1u;
-        };
-        auto bucket_of = [&](const Planned& p) -> uint32_t {
-            uint32_t bits = 0;
-            for (uint64_t l = p.len; l; l >>= 1) ++bits;  // 0..64
-            const uint32_t frac = bits > 4 ? (uint32_t)(p.len >> (bits - 5)) & (SUB - 1) : (uint32_t)p.len & (SUB - 1);
-            const uint32_t key = bits * SUB + frac;        // grows with the length
-            return group_of(p) * PER_GROUP + (PER_GROUP - 1u - key);
-        };
-        std::vector<uint32_t> start((size_t)n_groups * PER_GROUP + 1, 0);
-        for (const Planned& p : plan) {
-            ++start[bucket_of(p) + 1];
-            ++n_by_t[group_of(p)];
-        }
-        for (size_t b = 0; b + 1 < start.size(); ++b) start[b + 1] += start[b];
-        for (const Planned& p : plan) items[start[bucket_of(p)]++] = p.it;
+    // a query without a matching term still needs its (empty) result row written: the general kernel does that
+    auto group_of = [&](uint32_t i) -> uint32_t {
+        const uint32_t nt = st.unsorted[i].n_terms;
+        return nt >= 1u && nt <= fast_t ? nt - 1u : n_groups - 1u;
+    };
+    // counting sort on (group, length's bit count and its next four bits): order within 6 %, linear time
+    auto bucket_of = [&](uint32_t i) -> uint32_t {
+        const uint64_t len = st.item_len[i];
+        uint32_t bits = 0;
+        for (uint64_t l = len; l; l >>= 1) ++bits;  // 0..64
+        const uint32_t frac = bits > 4 ? (uint32_t)(len >> (bits - 5)) & (PLAN_SUB - 1) : (uint32_t)len & (PLAN_SUB - 1);
+        const uint32_t key = bits * PLAN_SUB + frac;  // grows with the length
+        return group_of(i) * PLAN_PER_GROUP + (PLAN_PER_GROUP - 1u - key);
+    };
+    const size_t nb = plan_buckets();
+    for (size_t b = 0; b <= nb; ++b) st.bucket[b] = 0;
+    for (uint32_t g = 0; g < 8; ++g) info.n_by_t[g] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        ++st.bucket[bucket_of(i) + 1];
+        ++info.n_by_t[group_of(i)];
     }
+    for (size_t b = 0; b < nb; ++b) st.bucket[b + 1] += st.bucket[b];
+    for (uint32_t i = 0; i < n; ++i) st.items[st.bucket[bucket_of(i)]++] = st.unsorted[i];
+    return SEBM25_OK;
+}
 
-    // ---- device buffers
-    const size_t qk = (size_t)n_queries * k, tk = (size_t)std::max(n_tmp, 1u) * k;
-    const bool dev_out = is_device_ptr(out_unit);
-    if (dev_out != is_device_ptr(out_score) || dev_out != is_device_ptr(out_matched) || dev_out != is_device_ptr(out_count) ||
-        (out_tie && dev_out != is_device_ptr(out_tie)))
-        return fail(ix, SEBM25_E_INVALID, "search: output arrays must be all host or all device memory");
-    HIP_TRY(ix, ix->q_items.ensure(items.size() * sizeof(QItem)));
-    HIP_TRY(ix, ix->q_terms.ensure(std::max<size_t>(flat.size(), 1) * 4));
-    HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
-    HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
-    HIP_TRY(ix, ix->t_unit.ensure(tk * 4));
-    HIP_TRY(ix, ix->t_score.ensure(tk * 8));
-    HIP_TRY(ix, ix->t_mat.ensure(tk * 4));
-    HIP_TRY(ix, ix->t_tie.ensure(tk * 4));
-    HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(n_tmp, 1u) * 4));
-    HIP_TRY(ix, ix->o_tie.ensure(qk * 4));
-    uint32_t *d_unit = out_unit, *d_mat = out_matched, *d_count = out_count, *d_tie = out_tie;
-    double* d_score = out_score;
-    if (!dev_out) {
-        HIP_TRY(ix, ix->o_unit.ensure(qk * 4));
-        HIP_TRY(ix, ix->o_score.ensure(qk * 8));
-        HIP_TRY(ix, ix->o_mat.ensure(qk * 4));
-        HIP_TRY(ix, ix->o_count.ensure((size_t)n_queries * 4));
-        d_unit = ix->o_unit.as<uint32_t>();
-        d_score = ix->o_score.as<double>();
-        d_mat = ix->o_mat.as<uint32_t>();
-        d_count = ix->o_count.as<uint32_t>();
-        d_tie = ix->o_tie.as<uint32_t>();
-    } else if (!d_tie) {
-        d_tie = ix->o_tie.as<uint32_t>();
-    }
+struct SearchBufs {  // device memory of one search call
+    QItem* items;
+    uint32_t *terms, *first, *nlists;
+    uint32_t *t_unit, *t_mat, *t_tie, *t_count;
+    double* t_score;
+};
+
+// launches scoring (+ the merge of split queries) for a finished plan; results land in d_*
+int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, const PlanStore& st, const PlanInfo& info,
+               const SearchBufs& b, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie, uint32_t* d_count) {
     phase_begin(ix, "search_plan_h2d");
-    HIP_TRY(ix, hipMemcpyAsync(ix->q_items.p, items.data(), items.size() * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
-    if (!flat.empty())
-        HIP_TRY(ix, hipMemcpyAsync(ix->q_terms.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ix->stream));
-    HIP_TRY(ix, hipMemcpyAsync(ix->q_first.p, first.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
-    HIP_TRY(ix, hipMemcpyAsync(ix->q_n.p, nlists.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(b.items, st.items, (size_t)info.n_items * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
+    if (info.n_flat)
+        HIP_TRY(ix, hipMemcpyAsync(b.terms, st.flat, (size_t)info.n_flat * 4, hipMemcpyHostToDevice, ix->stream));
+    if (info.n_tmp) {
+        HIP_TRY(ix, hipMemcpyAsync(b.first, st.first, (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(ix, hipMemcpyAsync(b.nlists, st.nlists, (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    }
     phase_end(ix);
 
     ScoreArgs a{};
@@ -838,20 +928,19 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
                       : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);
     a.unit_base = news ? ix->news_base : ix->web_base;
     a.news = news ? 1 : 0;
-    a.items = ix->q_items.as<QItem>();
-    a.q_terms = ix->q_terms.as<uint32_t>();
-    a.n_items = (uint32_t)items.size();
+    a.items = b.items;
+    a.q_terms = b.terms;
+    a.n_items = info.n_items;
     a.k = k;
     a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
-    a.tmp_unit = ix->t_unit.as<uint32_t>(); a.tmp_score = ix->t_score.as<double>(); a.tmp_matched = ix->t_mat.as<uint32_t>();
-    a.tmp_tie = ix->t_tie.as<uint32_t>(); a.tmp_count = ix->t_count.as<uint32_t>();
+    a.tmp_unit = b.t_unit; a.tmp_score = b.t_score; a.tmp_matched = b.t_mat; a.tmp_tie = b.t_tie; a.tmp_count = b.t_count;
     phase_begin(ix, "score_topk");
-    launch_score(a, n_by_t.data(), ix->score_impl, ix->stream);
+    launch_score(a, info.n_by_t, ix->score_impl, ix->stream);
     phase_end(ix);
-    if (n_tmp) {
+    if (info.n_tmp) {
         MergeArgs m{};
         m.n_queries = n_queries; m.k = k;
-        m.first = ix->q_first.as<uint32_t>(); m.n = ix->q_n.as<uint32_t>();
+        m.first = b.first; m.n = b.nlists;
         m.in_unit = a.tmp_unit; m.in_score = a.tmp_score; m.in_matched = a.tmp_matched; m.in_tie = a.tmp_tie; m.in_count = a.tmp_count;
         m.list_stride = 1;
         m.out_unit = d_unit; m.out_score = d_score; m.out_matched = d_mat; m.out_tie = d_tie; m.out_count = d_count;
@@ -860,6 +949,92 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
         phase_end(ix);
     }
     HIP_TRY(ix, hipGetLastError());
+    return SEBM25_OK;
+}
+
+int check_search_args(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
+                      uint32_t k, uint32_t max_k, const uint32_t* out_unit, const double* out_score,
+                      const uint32_t* out_matched, const uint32_t* out_count) {
+    if (!ix->built || !ix->finalized) return fail(ix, SEBM25_E_STATE, "search: index is not built and finalized");
+    if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
+        return fail(ix, SEBM25_E_INVALID, "search: source must be 1 (web) or 2 (news)");
+    if (k == 0 || k > max_k) return fail(ix, SEBM25_E_RANGE, "search: k must be in 1.." + std::to_string(max_k));
+    if (n_queries == 0) return SEBM25_OK;
+    if (!q_offsets || !out_unit || !out_score || !out_matched || !out_count)
+        return fail(ix, SEBM25_E_INVALID, "search: NULL argument");
+    if (is_device_ptr(q_offsets) || is_device_ptr(q_terms))
+        return fail(ix, SEBM25_E_INVALID, "search: query arrays must be host memory");
+    if (q_offsets[n_queries] && !q_terms) return fail(ix, SEBM25_E_INVALID, "search: q_terms is NULL");
+    return SEBM25_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
+                  uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie,
+                  uint32_t* out_count) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = check_search_args(ix, source, q_terms, q_offsets, n_queries, k, MAX_K, out_unit, out_score, out_matched, out_count);
+    if (rc || n_queries == 0) return rc;
+    if ((rc = refresh_host_ptrs(ix))) return rc;
+    phases_reset(ix);
+    const bool news = source == (int)SEBM25_SRC_NEWS;
+
+    // ---- plan (host storage grown on demand)
+    SearchPlanVecs& v = ix->plan_vecs;
+    v.flat.resize(std::max<size_t>(q_offsets[n_queries], 1));
+    for (std::vector<uint32_t>* x : {&v.q_toff, &v.q_nt, &v.q_ns, &v.first, &v.nlists}) x->resize(n_queries);
+    v.q_len.resize(n_queries);
+    v.bucket.resize(plan_buckets() + 1);
+    PlanStore st{};
+    st.flat = v.flat.data(); st.flat_cap = v.flat.size();
+    st.q_toff = v.q_toff.data(); st.q_nt = v.q_nt.data(); st.q_ns = v.q_ns.data(); st.q_len = v.q_len.data();
+    st.first = v.first.data(); st.nlists = v.nlists.data(); st.bucket = v.bucket.data();
+    PlanInfo info;
+    if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, ~0ull))) return rc;
+    v.items.resize(info.n_items); v.unsorted.resize(info.n_items); v.item_len.resize(info.n_items);
+    st.items = v.items.data(); st.unsorted = v.unsorted.data(); st.item_len = v.item_len.data(); st.item_cap = info.n_items;
+    if ((rc = plan_pass2(ix, news, n_queries, st, info))) return rc;
+
+    // ---- device buffers
+    const size_t qk = (size_t)n_queries * k, tk = (size_t)std::max(info.n_tmp, 1u) * k;
+    const bool dev_out = is_device_ptr(out_unit);
+    if (dev_out != is_device_ptr(out_score) || dev_out != is_device_ptr(out_matched) || dev_out != is_device_ptr(out_count) ||
+        (out_tie && dev_out != is_device_ptr(out_tie)))
+        return fail(ix, SEBM25_E_INVALID, "search: output arrays must be all host or all device memory");
+    HIP_TRY(ix, ix->q_items.ensure((size_t)info.n_items * sizeof(QItem)));
+    HIP_TRY(ix, ix->q_terms.ensure(std::max<size_t>(info.n_flat, 1) * 4));
+    HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->t_unit.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_score.ensure(tk * 8));
+    HIP_TRY(ix, ix->t_mat.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_tie.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(info.n_tmp, 1u) * 4));
+    uint32_t *d_unit = out_unit, *d_mat = out_matched, *d_count = out_count, *d_tie = out_tie;
+    double* d_score = out_score;
+    if (!dev_out) {
+        HIP_TRY(ix, ix->o_unit.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_score.ensure(qk * 8));
+        HIP_TRY(ix, ix->o_mat.ensure(qk * 4));
+        HIP_TRY(ix, ix->o_count.ensure((size_t)n_queries * 4));
+        d_unit = ix->o_unit.as<uint32_t>();
+        d_score = ix->o_score.as<double>();
+        d_mat = ix->o_mat.as<uint32_t>();
+        d_count = ix->o_count.as<uint32_t>();
+        if (out_tie) {
+            HIP_TRY(ix, ix->o_tie.ensure(qk * 4));
+            d_tie = ix->o_tie.as<uint32_t>();
+        }
+    }
+    SearchBufs b{ix->q_items.as<QItem>(), ix->q_terms.as<uint32_t>(), ix->q_first.as<uint32_t>(), ix->q_n.as<uint32_t>(),
+                 ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
+                 ix->t_score.as<double>()};
+    if ((rc = run_search(ix, news, n_queries, k, st, info, b, d_unit, d_score, d_mat, d_tie, d_count))) return rc;
     if (!dev_out) {
         if ((rc = copy_out(ix, out_unit, d_unit, qk * 4))) return rc;
         if ((rc = copy_out(ix, out_score, d_score, qk * 8))) return rc;
@@ -867,6 +1042,52 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
         if ((rc = copy_out(ix, out_tie, d_tie, qk * 4))) return rc;
         if ((rc = copy_out(ix, out_count, d_count, (size_t)n_queries * 4))) return rc;
     }
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    return SEBM25_OK;
+}
+
+int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets,
+                          uint32_t n_queries, uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched,
+                          uint32_t* out_tie, uint32_t* out_count) {
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search_noalloc: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = check_search_args(ix, source, q_terms, q_offsets, n_queries, k, NA_MAX_K, out_unit, out_score, out_matched, out_count);
+    if (rc || n_queries == 0) return rc;
+    if (n_queries > NA_MAX_QUERIES)
+        return fail(ix, SEBM25_E_RANGE, "search_noalloc: at most 1024 queries per call (use sebm25_search for larger batches)");
+    if (ix->device >= NA_MAX_DEVICES || !g_na_ptr[ix->device] || !ix->na_host)
+        return fail(ix, SEBM25_E_STATE, "search_noalloc: the fixed storage was not set up when the handle was created");
+    if (!ix->host_ptrs_valid && (ix->h_row_ptr.size() != (size_t)ix->V + 1 || ix->h_news_ptr.size() != ix->V))
+        return fail(ix, SEBM25_E_STATE, "search_noalloc: host copies of the list bounds are not reserved");
+    if ((rc = refresh_host_ptrs(ix))) return rc;  // copies only: the host arrays were sized by the build
+    if (!is_device_ptr(out_unit) || !is_device_ptr(out_score) || !is_device_ptr(out_matched) || !is_device_ptr(out_count) ||
+        (out_tie && !is_device_ptr(out_tie)))
+        return fail(ix, SEBM25_E_INVALID, "search_noalloc: output arrays must be device memory");
+    phases_reset(ix);
+    const bool news = source == (int)SEBM25_SRC_NEWS;
+    NaHost& h = *ix->na_host;
+    PlanStore st{};
+    st.flat = h.flat; st.flat_cap = NA_MAX_TERMS;
+    st.q_toff = h.q_toff; st.q_nt = h.q_nt; st.q_ns = h.q_ns; st.q_len = h.q_len;
+    st.first = h.first; st.nlists = h.nlists; st.bucket = h.bucket;
+    st.items = h.items; st.unsorted = h.unsorted; st.item_len = h.item_len; st.item_cap = NA_MAX_ITEMS;
+    PlanInfo info;
+    std::lock_guard<std::mutex> dev_lk(g_na_device_mu[ix->device]);
+    if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, NA_TMP_ENTRIES))) return rc;
+    if (info.n_items > NA_MAX_ITEMS) {  // too many unit ranges for the fixed item array: plan without splitting
+        for (uint32_t q = 0; q < n_queries; ++q) h.q_ns[q] = 1;
+        info.n_items = n_queries;
+        info.n_tmp = 0;
+    }
+    if ((rc = plan_pass2(ix, news, n_queries, st, info))) return rc;
+    unsigned char* base = g_na_ptr[ix->device];  // the device address, never the array's name
+    SearchBufs b{reinterpret_cast<QItem*>(base + NA_OFF_ITEMS), reinterpret_cast<uint32_t*>(base + NA_OFF_TERMS),
+                 reinterpret_cast<uint32_t*>(base + NA_OFF_FIRST), reinterpret_cast<uint32_t*>(base + NA_OFF_NLISTS),
+                 reinterpret_cast<uint32_t*>(base + NA_OFF_T_UNIT), reinterpret_cast<uint32_t*>(base + NA_OFF_T_MAT),
+                 reinterpret_cast<uint32_t*>(base + NA_OFF_T_TIE), reinterpret_cast<uint32_t*>(base + NA_OFF_T_COUNT),
+                 reinterpret_cast<double*>(base + NA_OFF_T_SCORE)};
+    if ((rc = run_search(ix, news, n_queries, k, st, info, b, out_unit, out_score, out_matched, out_tie, out_count))) return rc;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
 }

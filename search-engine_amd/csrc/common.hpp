@@ -146,6 +146,7 @@ void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_t
                          hipStream_t st);
 
 // scoring
+constexpr uint32_t SCORE_FAST_T = 4;  // queries of up to this many lists take the stepwise kernels
 struct QItem {
     uint32_t q;         // query index
     uint32_t term_off;  // into the flattened term list

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
 }
 
 // queries with at most FAST_T lists take the stepwise kernels below
-constexpr int FAST_T = 4;
+constexpr int FAST_T = (int)SCORE_FAST_T;
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const long long b = __double_as_longlong(v);

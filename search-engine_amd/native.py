@@ -68,7 +68,7 @@ EXPORTS = [
     "sebm25_create", "sebm25_destroy", "sebm25_last_error", "sebm25_set_stream", "sebm25_build_local",
     "sebm25_local_stats", "sebm25_finalize", "sebm25_build", "sebm25_get_stats", "sebm25_get_doc_len",
     "sebm25_set_idf", "sebm25_set_url_rank", "sebm25_set_unit_base", "sebm25_get_info", "sebm25_get_postings",
-    "sebm25_search", "sebm25_merge_topk", "sebm25_get_timings", "sebm25_enable_timing", "sebm25_zipf_cdf",
+    "sebm25_search", "sebm25_search_noalloc", "sebm25_merge_topk", "sebm25_get_timings", "sebm25_enable_timing", "sebm25_zipf_cdf",
     "sebm25_gen_corpus", "sebm25_gen_queries",
 ]
 
@@ -112,6 +112,7 @@ def lib():
     L.sebm25_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.sebm25_get_postings.argtypes = [vp, vp, vp, vp, vp]
     L.sebm25_search.argtypes = [vp, i32, vp, vp, u32, u32, vp, vp, vp, vp, vp]
+    L.sebm25_search_noalloc.argtypes = [vp, i32, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     L.sebm25_merge_topk.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.sebm25_get_timings.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32, C.POINTER(u32)]
     L.sebm25_enable_timing.argtypes = [vp, i32]
@@ -305,7 +306,13 @@ class Index:
         self._check(self._L.sebm25_set_unit_base(self._h, web_base, news_base))
 
     # -- search
-    def search(self, queries, k: int, source: int = SRC_WEB, out=None, want_tie: bool = False):
+    def search_noalloc(self, queries, k: int, out, source: int = SRC_WEB):
+        """`search` through the entry point that allocates nothing (sebm25_search_noalloc): `out`
+        must hold preallocated device tensors (unit, score, matched, count and optionally tie);
+        at most 1024 queries and k <= 256 per call."""
+        return self.search(queries, k, source=source, out=out, _entry="sebm25_search_noalloc")
+
+    def search(self, queries, k: int, source: int = SRC_WEB, out=None, want_tie: bool = False, _entry="sebm25_search"):
         """Batched top-k.  ``queries``: list of term-id sequences, or a 2-D uint32 array (one
         query per row).  -> dict(unit[Q,k], score[Q,k], matched[Q,k], count[Q], tie[Q,k]?).
         ``out`` may supply preallocated arrays/tensors under the same keys."""
@@ -325,7 +332,7 @@ class Index:
                        matched=np.empty((nq, k), np.uint32), count=np.empty(nq, np.uint32))
             if want_tie:
                 out["tie"] = np.empty((nq, k), np.uint32)
-        self._check(self._L.sebm25_search(self._h, source, q_terms.ctypes.data if len(q_terms) else None,
+        self._check(getattr(self._L, _entry)(self._h, source, q_terms.ctypes.data if len(q_terms) else None,
                                           q_off.ctypes.data, nq, k, _addr(out["unit"]), _addr(out["score"]),
                                           _addr(out["matched"]), _addr(out.get("tie")), _addr(out["count"])))
         return out
