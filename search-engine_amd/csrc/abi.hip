@@ -413,6 +413,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ctx.n_terms = V; ctx.n_docs = in->n_docs; ctx.n_articles = in->n_articles;
         ctx.check_order = unit_major ? 1u : 0u;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
+        ctx.doc_flags = in->n_docs ? flags_dev : nullptr;
         ctx.err = err_dev;
 
         static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6"};
@@ -458,7 +459,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
         HIP_TRY(ix, ix->scan_tmp.ensure(std::max(row_ptr_fill_tmp_words(V), postings_tmp_words(n_chunks)) * 4));
         phase_begin(ix, "postings");
-        launch_postings(sorted, R, chunk2, n_chunks, fmt, flags_dev, in->n_docs, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
+        launch_postings(sorted, R, chunk2, n_chunks, fmt, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
                         ix->df_local.as<uint32_t>(), scal, ix->scan_tmp.as<uint32_t>(), err_dev, ix->stream);
         phase_end(ix);
         phase_begin(ix, "term_stats");

@@ -399,6 +399,16 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             for (int j = 0; j < SORT_ITEMS; ++j)
                 if (l0 + (uint32_t)j * 64u >= n_tile) tfv[j] = 0;
         }
+        // status of the row's document (web rows; rows are unit-major or at least clustered, so this gather
+        // stays in cache): a doc that is not 'done' gets field code 3, which the posting pass turns into a hole
+        uint32_t dfl[SORT_ITEMS];
+        if (ctx.doc_flags) {
+    #pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) dfl[j] = ctx.doc_flags[min(unit[j], ctx.n_docs - 1u)];
+        } else {
+    #pragma unroll
+            for (int j = 0; j < SORT_ITEMS; ++j) dfl[j] = SEBM25_DOC_DONE;
+        }
         uint32_t carry_u = lo32(carry), carry_s = hi32(carry);
     #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
                 }
             }
             // same bits as RowFmt::pack(term, news, unit, field code, tf); field code: 1, 2, else 0
-            const uint32_t fc = field < 3u ? field : 0u;
+            const uint32_t fc = (!news & ((dfl[j] & SEBM25_DOC_DONE) == 0u)) ? 3u : field < 3u ? field : 0u;
             const uint64_t low = ((((uint64_t)(unit[j] >> 30) << 32) | ((unit[j] << 2) | fc)) << fmt.tf_bits) | tfv[j];
             const uint32_t hi = hi32(low) | (term[j] << term_sh) | (news ? src_hi : 0u);
             const uint32_t lo = lo32(low) | (news ? src_lo : 0u);
@@ -778,18 +788,15 @@ __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool 
 // Vector memory operations retire in issue order, so waiting for any load also waits for every
 // store issued before it.  The loop is therefore a three-stage pipeline in which loads are only
 // ever issued ahead of a batch's stores: while batch b is processed, the rows of batch b + 1 are
-// already in registers (their doc status bytes are gathered now) and the rows of batch b + 2 are
-// loaded.  Loads and slot stores are unconditional and fixed in number (clamped load addresses;
+// already in registers and the rows of batch b + 2 are loaded.  Loads and slot stores are unconditional and fixed in number (clamped load addresses;
 // the slot arrays are padded by POST_PAD entries, which take the stores of lanes behind the last
 // row), which lets the wait at the end of a batch leave the batch's own stores in flight.
 //
 // Per row the kernel computes one 32-bit word v = tenths(row) | differs-from-predecessor << 31;
 // what a run head needs to know about the rows behind it (do they continue the run, what do they
 // weigh) then comes from three one-lane shifts of v instead of three more rows to decode.
-template <bool HAS_FLAGS>
 __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, uint32_t R, uint32_t chunk_rows,
-                                                          uint32_t n_chunks, RowFmt fmt, const uint8_t* doc_flags,
-                                                          uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit,
+                                                          uint32_t n_chunks, RowFmt fmt, uint32_t n_terms, uint32_t* post_unit,
                                                           uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
                                                           uint32_t* df, uint4* partials, uint32_t* err) {
     // the range index is the same for the whole wave: tell the compiler, so that everything derived
@@ -813,7 +820,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
     const uint32_t ts_hi = rb.term_hi | rb.src_hi, ts_lo = rb.src_lo;
 
     uint64_t ra[RED_ROUNDS], rb1[RED_ROUNDS], rc[RED_ROUNDS];  // rows of batch b, b + 1, b + 2
-    uint32_t da[RED_ROUNDS], db[RED_ROUNDS];                   // doc status of batch b, b + 1
     // the row array is padded like the slot arrays: loads run up to 3 batches past the last row
     // without a clamp (what they bring is replaced below before it is looked at)
     auto load_rows = [&](uint32_t b0, uint64_t (&dst)[RED_ROUNDS]) {
@@ -821,18 +827,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) dst[j] = p[(uint32_t)j * 64u + lane];
     };
-    auto gather_flags = [&](const uint64_t (&src)[RED_ROUNDS], uint32_t (&dst)[RED_ROUNDS]) {
-#pragma unroll
-        for (int j = 0; j < RED_ROUNDS; ++j) {
-            if (HAS_FLAGS)
-                dst[j] = doc_flags[min(shr_lo32(src[j], rb.unit_sh) & rb.unit_mask, n_docs - 1u)];
-            else
-                dst[j] = SEBM25_DOC_DONE;
-        }
-    };
     load_rows(begin, ra);
     load_rows(begin + RED_BATCH, rb1);
-    gather_flags(ra, da);
     // as many stores (into the padding) behind these loads as a batch issues behind its loads;
     // the compiler must not move them ahead of the loads
     asm volatile("" ::: "memory");
@@ -844,7 +840,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
     asm volatile("" ::: "memory");
 
     for (uint32_t b0 = begin; b0 < end; b0 += RED_BATCH) {
-        gather_flags(rb1, db);
         load_rows(b0 + 2 * RED_BATCH, rc);
 
         // ---- phase 1: per row the word v, whether its term / its (term, source) differ from the
@@ -899,7 +894,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
             const uint32_t term = hi32(x0) >> rb.term_sh;
             const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
             const bool webhead = head & !news[j];
-            const bool kept = head & (news[j] | ((da[j] & SEBM25_DOC_DONE) != 0u));
+            // field code 3 marks the rows of a web doc whose status is not 'done' (set by the first sort pass)
+            const bool kept = head & (news[j] | ((shr_lo32(x0, rb.fc_sh) & 3u) != 3u));
             const uint64_t km = __ballot(kept), wm = __ballot(webhead);
             // a row whose term differs from the row before starts the term's slots (terms without rows
             // are filled in by k_row_ptr_fill); its first news row starts the term's news slots
@@ -949,7 +945,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
         for (int j = 0; j < RED_ROUNDS; ++j) {
             ra[j] = rb1[j];
             rb1[j] = rc[j];
-            da[j] = db[j];
         }
     }
     if (lane == 0) {
@@ -1021,21 +1016,16 @@ void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_
     hipLaunchKernelGGL(k_postings_fixup, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, fmt, post_w, err);
 }
 
-void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                     const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
-                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df, uint64_t* totals, uint32_t* tmp, uint32_t* err,
-                     hipStream_t st) {
+void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt, uint32_t n_terms,
+                     uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df,
+                     uint64_t* totals, uint32_t* tmp, uint32_t* err, hipStream_t st) {
     if (R == 0) return;
     uint4* partials = reinterpret_cast<uint4*>(tmp);  // postings_tmp_words(n_chunks) words
     const uint32_t wpb = RED_THREADS / 64;
     const dim3 grid((n_chunks + wpb - 1) / wpb), block(RED_THREADS);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(totals);
-    if (doc_flags && n_docs)
-        hipLaunchKernelGGL(k_postings<true>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
-                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, partials, err);
-    else
-        hipLaunchKernelGGL(k_postings<false>, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt,
-                           doc_flags, n_docs, n_terms, post_unit, post_w, row_ptr, news_ptr, df, partials, err);
+    hipLaunchKernelGGL(k_postings, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt, n_terms,
+                       post_unit, post_w, row_ptr, news_ptr, df, partials, err);
     hipLaunchKernelGGL(k_postings_totals, dim3(1), dim3(1024), 0, st, partials, n_chunks, tot);
 }
 

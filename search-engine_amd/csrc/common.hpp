@@ -16,7 +16,8 @@ namespace sebm25 {
 // ------------------------------------------------------------------ packed sort row ------
 // One token row as a 64-bit word, most significant field first:
 //   [ term : Tb ][ src : 1 ][ unit : Ub ][ fc : 2 ][ tf : Fb ]      Tb + Ub + Fb = 61
-// src: 0 web, 1 news.  fc: 0 = weight 1.0, 1 = title (3.2), 2 = description (1.7).
+// src: 0 web, 1 news.  fc: 0 = weight 1.0, 1 = title (3.2), 2 = description (1.7), 3 = row of a web doc
+// whose status is not 'done' (counts toward df, yields no posting).
 // Sorting on the top Tb + 1 + Ub bits orders rows by (term, source, unit).
 struct RowFmt {
     int term_bits, unit_bits, tf_bits;
@@ -108,6 +109,7 @@ struct BuildCtx {
     uint32_t n_terms, n_docs, n_articles;
     uint32_t check_order;   // rows declared unit-major: verify
     uint32_t* doc_len;      // [n_docs] accumulators (zeroed)
+    const uint8_t* doc_flags;  // [n_docs] SEBM25_DOC_* bits or null (every doc 'done'); read by the first sort pass
     uint32_t* err;          // device error word
 };
 
@@ -127,9 +129,8 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
 
-void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt,
-                     const uint8_t* doc_flags, uint32_t n_docs, uint32_t n_terms, uint32_t* post_unit, uint32_t* post_w,
-                     uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
+void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt, uint32_t n_terms,
+                     uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
                      uint64_t* totals /* [0] kept, [1] web heads, [5] kept web; zeroed */,
                      uint32_t* tmp /* postings_tmp_words(n_chunks) words, 16-byte aligned */, uint32_t* err, hipStream_t st);
 size_t postings_tmp_words(uint32_t n_chunks);

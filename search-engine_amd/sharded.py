@@ -66,31 +66,53 @@ class ShardedIndex:
         return t
 
     # ---- scoring
-    def search(self, queries, k, source=SRC_WEB):
-        """-> dict(unit, score, matched, count) of the global top-k (numpy arrays, global unit ids),
-        the same on every rank."""
+    def _pack(self, nq, k):
+        """One byte buffer per rank holding score f64[nq, k] | unit | matched | tie i32[nq, k] | count i32[nq], and
+        the buffer that receives every rank's copy: the whole exchange of a search is ONE all-gather."""
+        key = (nq, k)
+        if getattr(self, "_pack_key", None) != key:
+            n = nq * k
+            self._off = dict(score=0, unit=8 * n, matched=12 * n, tie=16 * n, count=20 * n)
+            nbytes = (20 * n + 4 * nq + 7) // 8 * 8
+            self._mine = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._all = torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device)
+            self._pack_key = key
+        return self._mine, self._all
+
+    def _views(self, buf, nq, k, lists=None):
+        """Typed views of one packed buffer (lists=None) or of the gathered buffers, list-major copies."""
+        n = nq * k
+        out = {}
+        for name, dt, cnt, shape in (("score", torch.float64, n, (nq, k)), ("unit", torch.int32, n, (nq, k)),
+                                     ("matched", torch.int32, n, (nq, k)), ("tie", torch.int32, n, (nq, k)),
+                                     ("count", torch.int32, nq, (nq,))):
+            o, nb = self._off[name], cnt * (8 if dt == torch.float64 else 4)
+            if lists is None:
+                out[name] = buf[o:o + nb].view(dt).view(shape)
+            else:
+                out[name] = buf.view(lists, -1)[:, o:o + nb].contiguous().view(dt).view((lists,) + shape)
+        return out
+
+    def search(self, queries, k, source=SRC_WEB, out_device=False):
+        """-> dict(unit, score, matched, count) of the global top-k (global unit ids), the same on every
+        rank: numpy arrays, or tensors on `device` with out_device=True."""
         e = self.engine
         nq = len(queries)
-        dev = self.device
-        loc = dict(unit=torch.empty((nq, k), dtype=torch.int32, device=dev),
-                   score=torch.empty((nq, k), dtype=torch.float64, device=dev),
-                   matched=torch.empty((nq, k), dtype=torch.int32, device=dev),
-                   tie=torch.empty((nq, k), dtype=torch.int32, device=dev),
-                   count=torch.empty(nq, dtype=torch.int32, device=dev))
+        mine, gathered = self._pack(nq, k)
+        loc = self._views(mine, nq, k)
         e.search(queries, k, source=source, out=loc)
         if self.world == 1:
-            return {key: _to_numpy(v) for key, v in loc.items() if key != "tie"}
-        gathered = {}
-        for key, v in loc.items():
-            buf = torch.empty((self.world,) + tuple(v.shape), dtype=v.dtype, device=dev)
-            dist.all_gather(list(buf.unbind(0)), v.contiguous(), group=self.group)   # per-shard top-k lists
-            gathered[key] = buf
-        out = dict(unit=torch.empty_like(loc["unit"]), score=torch.empty_like(loc["score"]),
-                   matched=torch.empty_like(loc["matched"]), tie=torch.empty_like(loc["tie"]),
-                   count=torch.empty_like(loc["count"]))
-        e.merge_topk(self.world, nq, k, gathered["unit"], gathered["score"], gathered["matched"], gathered["tie"],
-                     gathered["count"], out=out)
-        return {key: _to_numpy(v) for key, v in out.items() if key != "tie"}
+            res = loc
+        else:
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)    # per-shard top-k lists, one collective
+            g = self._views(gathered, nq, k, lists=self.world)
+            res = dict(unit=torch.empty_like(loc["unit"]), score=torch.empty_like(loc["score"]),
+                       matched=torch.empty_like(loc["matched"]), tie=torch.empty_like(loc["tie"]),
+                       count=torch.empty_like(loc["count"]))
+            e.merge_topk(self.world, nq, k, g["unit"], g["score"], g["matched"], g["tie"], g["count"], out=res)
+        if out_device:
+            return {key: v for key, v in res.items() if key != "tie"}
+        return {key: _to_numpy(v) for key, v in res.items() if key != "tie"}
 
 
 def _to_numpy(t: torch.Tensor) -> np.ndarray:

@@ -4,8 +4,6 @@ over the reference's table shapes (alembic/versions/0001_initial_schema.py:33-51
 0007_unify_news_tokens.py:19-27).  sqlite is a stand-in for PostgreSQL, which is not available
 here: it checks GROUP BY / COUNT(DISTINCT) / NULL / LEFT JOIN + COALESCE / ORDER BY .. LIMIT
 semantics, not PostgreSQL's NUMERIC arithmetic.  No GPU."""
-import sqlite3
-
 import numpy as np
 import pytest
 
@@ -13,83 +11,7 @@ from oracle import oracle as O
 
 from helpers import assert_topk_valid, small_corpus
 
-DDL = """
-CREATE TABLE documents (id INTEGER PRIMARY KEY, url TEXT, title TEXT, description TEXT, word_count INTEGER, status TEXT);
-CREATE TABLE news_articles (url TEXT PRIMARY KEY, title TEXT, description TEXT);
-CREATE TABLE tokens (doc_id INTEGER, term TEXT, field INTEGER, frequency INTEGER, article_url TEXT, source_type INTEGER DEFAULT 1);
-CREATE TABLE term_statistics (term TEXT PRIMARY KEY, doc_frequency INTEGER, idf REAL, avg_doc_len REAL);
-CREATE INDEX idx_tokens_term ON tokens(term);
-"""
-
-STATS_SQL = """
-INSERT INTO term_statistics(term, doc_frequency, idf, avg_doc_len)
-SELECT t.term, COUNT(DISTINCT t.doc_id),
-       LN((? - COUNT(DISTINCT t.doc_id) + 0.5) / (COUNT(DISTINCT t.doc_id) + 0.5) + 1), ?
-FROM tokens t GROUP BY t.term
-"""
-
-WEB_SQL = """
-WITH scored AS (
-  SELECT d.id AS id, d.url AS url,
-         SUM(t.frequency * COALESCE(ts.idf, 1.0) * CASE t.field WHEN 1 THEN 3.2 WHEN 2 THEN 1.7 ELSE 1.0 END) AS token_score,
-         COUNT(DISTINCT t.term) AS matched_terms
-  FROM tokens t JOIN documents d ON d.id = t.doc_id
-  LEFT JOIN term_statistics ts ON ts.term = t.term
-  WHERE d.status = 'done' AND t.term IN ({ph})
-  GROUP BY d.id, d.title, d.description, d.url)
-SELECT id, token_score, matched_terms FROM scored ORDER BY token_score DESC, url ASC LIMIT ?
-"""
-
-NEWS_SQL = """
-SELECT na.url, SUM(t.frequency * COALESCE(ts.idf, 1.0)) AS token_score, COUNT(DISTINCT t.term) AS matched_terms
-FROM tokens t JOIN news_articles na ON na.url = t.article_url
-LEFT JOIN term_statistics ts ON ts.term = t.term
-WHERE t.source_type = 2 AND t.term IN ({ph})
-GROUP BY na.title, na.description, na.url
-ORDER BY token_score DESC, na.url ASC LIMIT ?
-"""
-
-
-def term_text(t):
-    return "t%07d" % t
-
-
-def doc_url(d):
-    return "https://s.test/%012d" % d      # byte order == doc id order
-
-
-def art_url(a):
-    return "https://n.test/%012d" % a
-
-
-def load_db(c, doc_flags=None, stale_terms=()):
-    db = sqlite3.connect(":memory:")
-    db.executescript(DDL)
-    nd = c["n_docs"]
-    for d in range(nd):
-        fl = 1 if doc_flags is None else int(doc_flags[d])
-        wc = None if fl & 2 else int(c["word_count"][d])
-        db.execute("INSERT INTO documents VALUES (?,?,?,?,?,?)",
-                   (d, doc_url(d), "", "", wc, "done" if fl & 1 else "processing"))
-    for a in range(c["n_articles"]):
-        db.execute("INSERT INTO news_articles VALUES (?,?,?)", (art_url(a), "", ""))
-    rows = []
-    for t, u, f, m in zip(c["term_id"].tolist(), c["unit_id"].tolist(), c["tf"].tolist(), c["meta"].tolist()):
-        st, field = m & 3, m >> 2
-        if st == 1:
-            rows.append((u, term_text(t), field, f, None, 1))
-        else:
-            rows.append((None, term_text(t), field, f, art_url(u), 2))      # news rows carry no doc id
-    db.executemany("INSERT INTO tokens VALUES (?,?,?,?,?,?)", rows)
-    # the statistics job, statement for statement
-    avg = db.execute("SELECT AVG(word_count) FROM documents WHERE status='done'").fetchone()[0] or 0.0
-    total = db.execute("SELECT COUNT(*) FROM documents WHERE status='done'").fetchone()[0] or 1
-    db.execute("DELETE FROM term_statistics")
-    db.execute(STATS_SQL, (total, avg))
-    for t in stale_terms:
-        db.execute("DELETE FROM term_statistics WHERE term = ?", (term_text(t),))
-    db.commit()
-    return db, total, avg
+from oracle.sqlite_standin import NEWS_SQL, WEB_SQL, load_db, term_text
 
 
 @pytest.fixture(scope="module")
