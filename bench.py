@@ -287,7 +287,7 @@ def main():
         "sort_hist_0": ("k_sort_hist<0>", 4), "sort_hist_1": ("k_sort_hist<2>", 8),
         "sort_scatter_0": ("k_sort_scatter_tile<0>", 13 + 8),   # raw row in, packed row out
         "sort_scatter_1": ("k_sort_scatter_tile<2>", 8 + 8),    # packed row in, packed row out
-        "postings": ("k_postings<true>", 8 + 8),                # packed row in, posting slot out (+ a status byte gather)
+        "postings": ("k_postings", 8 + 8),                      # packed row in, posting slot out
     }
     traffic_db = load_traffic()
     build_traffic = traffic_db.get("build", {}) if traffic_db.get("build", {}).get("rows") == int(info.n_rows) else {}
@@ -336,7 +336,8 @@ def main():
     if not args.no_variants:
         ph2 = kernel_phases(False, 5)
         out["variant_without_doc_flags"] = {"device_ms_sum_of_phases": sum(ph2.values()),
-                                            "postings_ms": ph2.get("postings"), "note": "k_postings<false>: no status gather"}
+                                            "sort_scatter_0_ms": ph2.get("sort_scatter_0"),
+                                            "note": "doc_flags = NULL: the first sort pass reads no status bytes"}
 
     # ---- batched scoring
     if not args.no_query:
@@ -394,7 +395,7 @@ def main():
         tq = traffic_db.get("query", {})
         if tq.get("postings_scored_per_batch") == sum_df:
             q_traffic = tq.get("hbm_bytes_per_launch")
-        kq = f"k_score_step<3, RegTopK<true>, true, 5>" if args.k <= 64 else "k_score_step<3, TopK<...>, true, ...>"
+        kq = "k_score_step<3, RegTopK<true>, true, 5>" if args.k <= 64 else "k_score_step<3, TopK<320, true>, true, 3>"
         out["query"] = {
             "metric": f"top{args.k}_queries_per_s", "value": args.queries / (q_ms * 1e-3), "unit": "queries/s",
             "ms_per_batch": q_ms, "queries": args.queries, "terms_per_query": args.terms_per_query, "k": args.k,
