@@ -15,7 +15,7 @@ namespace {
 thread_local std::string g_thread_err;
 
 constexpr uint32_t MAX_K = 2048;
-constexpr uint32_t MAX_QUERY_TERMS = 64;
+constexpr uint32_t MAX_QUERY_TERMS = 255;  // the matched-terms count of a result is kept in 8 bits
 constexpr uint32_t RED_MAX_CHUNKS = 16384;  // wavefronts
 }  // namespace
 
@@ -45,7 +45,6 @@ struct sebm25_index {
     RowFmt fmt{1, 1, 59};
     uint32_t n_pass = 0;
     int sort_bits = SORT_MAX_BITS;  // widest radix digit (tuning knob: SEBM25_SORT_BITS = 4..10)
-    int score_impl = 0;             // 0: stepwise kernels with bound-based filtering; 1: the older hashed-accumulator kernel (SEBM25_SCORE_IMPL=hash)
     bool big_weights = false;       // some posting weight needs more than 16 bits: queries take the general kernel
     uint64_t P = 0, P_web = 0, WH = 0;
     uint32_t web_base = 0, news_base = 0;
@@ -152,6 +151,21 @@ int na_setup_device(sebm25_index* ix, int device) {
 
 
 namespace {
+
+// No exception crosses the C boundary: allocation failures of the host containers become SEBM25_E_NOMEM.
+int fail_quiet(sebm25_index* ix, int code, const char* msg) noexcept {
+    try {
+        return fail(ix, code, msg);
+    } catch (...) {
+        return code;
+    }
+}
+#define ABI_TRY try {
+#define ABI_CATCH(ix)                                                                 \
+    }                                                                                 \
+    catch (const std::bad_alloc&) { return fail_quiet(ix, SEBM25_E_NOMEM, "out of host memory"); } \
+    catch (const std::exception& e) { return fail_quiet(ix, SEBM25_E_INTERNAL, e.what()); }        \
+    catch (...) { return fail_quiet(ix, SEBM25_E_INTERNAL, "unknown exception"); }
 
 bool is_device_ptr(const void* p) {
     if (!p) return false;
@@ -416,10 +430,14 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ctx.doc_flags = in->n_docs ? flags_dev : nullptr;
         ctx.err = err_dev;
 
-        static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6"};
-        static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6"};
-        static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6"};
-
+        // at most ceil(54 key bits / 4-bit digits) = 14 passes
+        static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6", "sort_hist_7",
+                                           "sort_hist_8", "sort_hist_9", "sort_hist_10", "sort_hist_11", "sort_hist_12", "sort_hist_13", "sort_hist_14", "sort_hist_15"};
+        static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6", "sort_scan_7",
+                                           "sort_scan_8", "sort_scan_9", "sort_scan_10", "sort_scan_11", "sort_scan_12", "sort_scan_13", "sort_scan_14", "sort_scan_15"};
+        static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6", "sort_scatter_7",
+                                           "sort_scatter_8", "sort_scatter_9", "sort_scatter_10", "sort_scatter_11", "sort_scatter_12", "sort_scatter_13", "sort_scatter_14", "sort_scatter_15"};
+        if (n_pass > 16) return fail(ix, SEBM25_E_INTERNAL, "build: more than 16 sort passes");
         const uint64_t* src_packed = nullptr;
         uint64_t* bufs[2] = {ix->sortA.as<uint64_t>(), ix->sortB.as<uint64_t>()};
         int shift = key_lo;
@@ -510,6 +528,7 @@ extern "C" {
 const char* sebm25_last_error(const sebm25_index* ix) { return ix ? ix->err.c_str() : g_thread_err.c_str(); }
 
 int sebm25_create(int device, sebm25_index** out) {
+    ABI_TRY
     if (!out) return fail(nullptr, SEBM25_E_INVALID, "create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -521,7 +540,6 @@ int sebm25_create(int device, sebm25_index** out) {
     sebm25_index* ix = new (std::nothrow) sebm25_index();
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
-    if (const char* e = getenv("SEBM25_SCORE_IMPL")) ix->score_impl = strcmp(e, "hash") == 0 ? 1 : 0;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     {
         // set-up of sebm25_search_noalloc: this GPU's address of the fixed device array and the pinned host plan storage
@@ -541,6 +559,7 @@ int sebm25_create(int device, sebm25_index** out) {
     }
     *out = ix;
     return SEBM25_OK;
+    ABI_CATCH(nullptr)
 }
 
 void sebm25_destroy(sebm25_index* ix) {
@@ -578,6 +597,7 @@ int sebm25_enable_timing(sebm25_index* ix, int on) {
 }
 
 int sebm25_get_timings(sebm25_index* ix, const char** names_out, float* ms_out, uint32_t cap, uint32_t* n_out) {
+    ABI_TRY
     if (!ix || !n_out) return fail(ix, SEBM25_E_INVALID, "get_timings: NULL argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -589,32 +609,40 @@ int sebm25_get_timings(sebm25_index* ix, const char** names_out, float* ms_out, 
         if (ms_out) ms_out[i] = ix->timer.ms[i];
     }
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_build_local(sebm25_index* ix, const sebm25_rows* rows) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "build_local: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     return do_build_local(ix, rows);
+    ABI_CATCH(ix)
 }
 
 int sebm25_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* totals_global) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "finalize: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     return do_finalize(ix, df_global, totals_global);
+    ABI_CATCH(ix)
 }
 
 int sebm25_build(sebm25_index* ix, const sebm25_rows* rows) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "build: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     int rc = do_build_local(ix, rows);
     if (rc) return rc;
     return do_finalize(ix, nullptr, nullptr);
+    ABI_CATCH(ix)
 }
 
 int sebm25_local_stats(sebm25_index* ix, uint32_t* df_out, sebm25_doc_totals* totals_out) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "local_stats: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -624,10 +652,12 @@ int sebm25_local_stats(sebm25_index* ix, uint32_t* df_out, sebm25_doc_totals* to
     if (totals_out) *totals_out = ix->local_totals;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_get_stats(sebm25_index* ix, uint32_t* df_out, double* idf_out, uint32_t* term_rows_out, uint64_t* n_docs_out,
                      double* avgdl_out) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_stats: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -640,9 +670,11 @@ int sebm25_get_stats(sebm25_index* ix, uint32_t* df_out, double* idf_out, uint32
     if (avgdl_out) *avgdl_out = ix->avgdl;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_get_doc_len(sebm25_index* ix, uint32_t* doc_len_out) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_doc_len: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -651,9 +683,11 @@ int sebm25_get_doc_len(sebm25_index* ix, uint32_t* doc_len_out) {
     if (rc) return rc;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present) {
+    ABI_TRY
     if (!ix || !idf) return fail(ix, SEBM25_E_INVALID, "set_idf: NULL argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -670,9 +704,11 @@ int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present) 
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     ix->finalized = true;
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "set_url_rank: handle is NULL");
     if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
         return fail(ix, SEBM25_E_INVALID, "set_url_rank: source must be 1 (web) or 2 (news)");
@@ -692,6 +728,7 @@ int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank) {
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     has = true;
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base) {
@@ -703,6 +740,7 @@ int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base
 }
 
 int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
+    ABI_TRY
     if (!ix || !out) return fail(ix, SEBM25_E_INVALID, "get_info: NULL argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -718,10 +756,12 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     out->tf_bits = (uint32_t)ix->fmt.tf_bits;
     out->sort_passes = ix->n_pass;
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr, uint32_t* post_unit,
                         uint32_t* post_weight) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "get_postings: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -765,6 +805,7 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
     if (post_unit && n) HIP_TRY(ix, hipMemcpy(post_unit, cu.data(), n * 4, hipMemcpyDefault));
     if (post_weight && n) HIP_TRY(ix, hipMemcpy(post_weight, cw.data(), n * 4, hipMemcpyDefault));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 // ---------------------------------------------------------------------------- search -------
@@ -819,7 +860,7 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
             len += list_len(t);
         }
         if (nf - start > MAX_QUERY_TERMS)
-            return fail(ix, SEBM25_E_RANGE, "search: more than 64 distinct matching terms in one query");
+            return fail(ix, SEBM25_E_RANGE, "search: more than 255 distinct matching terms in one query");
         st.q_toff[q] = (uint32_t)start;
         st.q_nt[q] = (uint32_t)(nf - start);
         st.q_len[q] = len;
@@ -936,7 +977,7 @@ int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, cons
     a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
     a.tmp_unit = b.t_unit; a.tmp_score = b.t_score; a.tmp_matched = b.t_mat; a.tmp_tie = b.t_tie; a.tmp_count = b.t_count;
     phase_begin(ix, "score_topk");
-    launch_score(a, info.n_by_t, ix->score_impl, ix->stream);
+    launch_score(a, info.n_by_t, ix->stream);
     phase_end(ix);
     if (info.n_tmp) {
         MergeArgs m{};
@@ -976,6 +1017,7 @@ extern "C" {
 int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
                   uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie,
                   uint32_t* out_count) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1045,11 +1087,13 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     }
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets,
                           uint32_t n_queries, uint32_t k, uint32_t* out_unit, double* out_score, uint32_t* out_matched,
                           uint32_t* out_tie, uint32_t* out_count) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "search_noalloc: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1091,11 +1135,13 @@ int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms,
     if ((rc = run_search(ix, news, n_queries, k, st, info, b, out_unit, out_score, out_matched, out_tie, out_count))) return rc;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 int sebm25_merge_topk(sebm25_index* ix, uint32_t n_lists, uint32_t n_queries, uint32_t k, const uint32_t* in_unit,
                       const double* in_score, const uint32_t* in_matched, const uint32_t* in_tie, const uint32_t* in_count,
                       uint32_t* out_unit, double* out_score, uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count) {
+    ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "merge_topk: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1154,28 +1200,34 @@ int sebm25_merge_topk(sebm25_index* ix, uint32_t n_lists, uint32_t n_queries, ui
     }
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 // ---------------------------------------------------------------------------- corpus -------
 
 int sebm25_zipf_cdf(uint32_t n_terms, double zipf_s, uint32_t* cdf_out) {
+    ABI_TRY
     if (!cdf_out || n_terms == 0) return fail(nullptr, SEBM25_E_INVALID, "zipf_cdf: NULL output or empty vocabulary");
     host_zipf_cdf(n_terms, zipf_s, cdf_out);
     return SEBM25_OK;
+    ABI_CATCH(nullptr)
 }
 
 int sebm25_gen_queries(uint64_t seed, uint32_t n_terms, double zipf_s, uint32_t min_rank, uint32_t n_queries,
                        uint32_t terms_per_query, uint32_t* q_terms_out) {
+    ABI_TRY
     if (!q_terms_out || n_terms == 0) return fail(nullptr, SEBM25_E_INVALID, "gen_queries: NULL output or empty vocabulary");
     std::vector<uint32_t> cdf(n_terms);
     host_zipf_cdf(n_terms, zipf_s, cdf.data());
     if (host_gen_queries(seed, n_terms, cdf.data(), min_rank, n_queries, terms_per_query, q_terms_out))
         return fail(nullptr, SEBM25_E_RANGE, "gen_queries: vocabulary too small for terms_per_query distinct terms");
     return SEBM25_OK;
+    ABI_CATCH(nullptr)
 }
 
 int sebm25_gen_corpus(sebm25_index* ix, const sebm25_corpus_spec* spec, uint64_t* n_rows_out, uint32_t* term_id,
                       uint32_t* unit_id, uint32_t* tf, uint8_t* meta, uint32_t* word_count) {
+    ABI_TRY
     if (!ix || !spec || !n_rows_out) return fail(ix, SEBM25_E_INVALID, "gen_corpus: NULL argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
@@ -1215,6 +1267,7 @@ int sebm25_gen_corpus(sebm25_index* ix, const sebm25_corpus_spec* spec, uint64_t
     HIP_TRY(ix, hipGetLastError());
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
+    ABI_CATCH(ix)
 }
 
 }  // extern "C"

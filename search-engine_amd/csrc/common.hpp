@@ -151,7 +151,7 @@ constexpr uint32_t SCORE_FAST_T = 4;  // queries of up to this many lists take t
 struct QItem {
     uint32_t q;         // query index
     uint32_t term_off;  // into the flattened term list
-    uint32_t n_terms;   // 1..64
+    uint32_t n_terms;   // 0..255
     uint32_t unit_lo, unit_hi;
     uint32_t out_slot;  // result list index (direct output row or temporary slice list)
     uint32_t direct;    // 1: writes the final result row
@@ -177,7 +177,7 @@ struct ScoreArgs {
     double* tmp_score;
 };
 // n_by_t[i], i < score_fast_max_terms(): items with i + 1 lists; n_by_t[score_fast_max_terms()]: the rest
-void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, int impl, hipStream_t st);
+void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, hipStream_t st);
 uint32_t score_fast_max_terms();
 struct MergeArgs {
     uint32_t n_queries, k;

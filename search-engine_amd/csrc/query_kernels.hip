@@ -3,13 +3,14 @@
 //   score(unit) = SUM over query terms of idf_used[t] * w(t, unit),  matched = COUNT(DISTINCT term),
 //   ORDER BY score DESC, url ASC LIMIT k.
 //
-// One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a
-// range of slots sorted by unit (a few of them holes that carry no posting), so the wave walks all lists of the query in step through a window of WIN consecutive
-// unit ids whose accumulators live in LDS: 64 coalesced postings per list per load, a
-// "touched" bitmap (one 32-bit word per lane) instead of clearing accumulators, and a
-// candidate buffer that is cut back to the best k by a wave-wide bitonic sort whenever it
-// fills.  Lists are added in query-term order, so a score is the same double sum whatever the
-// work split.  No workgroup barriers: a wave's LDS operations complete in issue order.
+// One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a range of
+// slots sorted by unit (a few of them holes that carry no posting).  Queries of up to four lists take the
+// stepwise kernel (k_score_step): all lists advance together to a common frontier, 64 coalesced slots per
+// list per load, integer accumulators in a small LDS hash table, and the best k in registers (k <= 64) or in
+// an LDS buffer that is merged, not re-sorted, when it fills.  Longer queries take the general kernel
+// (k_score), which walks windows of WIN consecutive unit ids with directly indexed accumulators.  Lists are
+// always added in query-term order, so a score is the same double sum whatever the work split.  No
+// workgroup barriers: a wave's LDS operations complete in issue order.
 #include "common.hpp"
 
 namespace sebm25 {
@@ -197,6 +198,9 @@ __device__ __forceinline__ uint32_t lower_bound_unit(const uint32_t* post_unit, 
     return b;
 }
 
+// The general form: any number of lists up to 64 * SCORE_LIST_BLOCKS.  Lane l keeps the cursors of lists
+// l, l + 64, l + 128, ...
+constexpr int SCORE_LIST_BLOCKS = 4;
 template <int CAP>
 __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
     __shared__ __align__(16) double acc[WIN];
@@ -208,16 +212,21 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
     const uint32_t lane = lane_id();
     const uint32_t T = it.n_terms;
 
-    // lane t < T keeps the cursor of list t
-    uint32_t my_cur = 0, my_end = 0;
-    double my_idf = 0.0;
-    if (lane < T) {
-        const uint32_t term = a.q_terms[it.term_off + lane];
-        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
-        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
-        my_end = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
-        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
+    uint32_t my_cur[SCORE_LIST_BLOCKS], my_end[SCORE_LIST_BLOCKS];
+    double my_idf[SCORE_LIST_BLOCKS];
+#pragma unroll
+    for (int blk = 0; blk < SCORE_LIST_BLOCKS; ++blk) {
+        my_cur[blk] = my_end[blk] = 0;
+        my_idf[blk] = 0.0;
+        const uint32_t t = (uint32_t)blk * 64u + lane;
+        if (t < T) {
+            const uint32_t term = a.q_terms[it.term_off + t];
+            const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+            const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+            my_cur[blk] = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+            my_end[blk] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, my_cur[blk], e, it.unit_hi);
+            my_idf[blk] = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
+        }
     }
     touched[lane] = 0;
     TopK<CAP> tk;
@@ -226,42 +235,50 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
 
     while (true) {
         // window start: the smallest unit any list still has to deliver
-        uint32_t nxt = (lane < T && my_cur < my_end) ? a.post_unit[my_cur] : 0xFFFFFFFFu;
+        uint32_t nxt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int blk = 0; blk < SCORE_LIST_BLOCKS; ++blk)
+            if (my_cur[blk] < my_end[blk]) nxt = min(nxt, a.post_unit[my_cur[blk]]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor(nxt, off));
         if (nxt == 0xFFFFFFFFu) break;
         const uint32_t base = nxt & ~31u;
         const uint64_t wend = (uint64_t)base + WIN;
 
-        for (uint32_t t = 0; t < T; ++t) {
-            uint32_t c = __shfl(my_cur, (int)t);
-            const uint32_t e = __shfl(my_end, (int)t);
-            const double idf = __shfl(my_idf, (int)t);
-            while (true) {
-                const uint32_t i = c + lane;
-                const bool valid = i < e;
-                const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
-                const bool in = valid && (uint64_t)u < wend;
-                const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-                const uint32_t w = in ? a.post_w[i] : POST_HOLE;
-                if (w != POST_HOLE) {  // a hole only moves the cursor
-                    const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
-                    const uint32_t idx = u - base;
-                    const uint32_t bit = 1u << (idx & 31u);
-                    const uint32_t old = atomicOr(&touched[idx >> 5], bit);
-                    if (old & bit) {
-                        acc[idx] = __dadd_rn(acc[idx], v);
-                        cnt[idx] = (unsigned char)(cnt[idx] + 1);
-                    } else {
-                        acc[idx] = v;
-                        cnt[idx] = 1;
+#pragma unroll
+        for (int blk = 0; blk < SCORE_LIST_BLOCKS; ++blk) {
+            if ((uint32_t)blk * 64u >= T) break;
+            const uint32_t nl = min(64u, T - (uint32_t)blk * 64u);
+            for (uint32_t l = 0; l < nl; ++l) {  // lists in query-term order
+                uint32_t c = __shfl(my_cur[blk], (int)l);
+                const uint32_t e = __shfl(my_end[blk], (int)l);
+                const double idf = __shfl(my_idf[blk], (int)l);
+                while (true) {
+                    const uint32_t i = c + lane;
+                    const bool valid = i < e;
+                    const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
+                    const bool in = valid && (uint64_t)u < wend;
+                    const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                    const uint32_t w = in ? a.post_w[i] : POST_HOLE;
+                    if (w != POST_HOLE) {  // a hole only moves the cursor
+                        const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
+                        const uint32_t idx = u - base;
+                        const uint32_t bit = 1u << (idx & 31u);
+                        const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                        if (old & bit) {
+                            acc[idx] = __dadd_rn(acc[idx], v);
+                            cnt[idx] = (unsigned char)(cnt[idx] + 1);
+                        } else {
+                            acc[idx] = v;
+                            cnt[idx] = 1;
+                        }
                     }
+                    c += n_in;
+                    if (n_in < 64) break;
                 }
-                c += n_in;
-                if (n_in < 64) break;
+                if (lane == l) my_cur[blk] = c;
+                __builtin_amdgcn_wave_barrier();
             }
-            if (lane == t) my_cur = c;
-            __builtin_amdgcn_wave_barrier();
         }
 
         // harvest the window: lane l owns units [base + 32 l, base + 32 l + 32)
@@ -302,169 +319,14 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// Fast path in posting space.  Instead of windows of unit ids (whose lanes are mostly idle when the
-// lists are sparse: a 512-unit window holds about 14 postings of a typical list), a step takes,
-// from every list, all slots up to a frontier F = the smallest "last unit of the chunk in
-// registers" over the lists.  Every posting of a unit <= F is then in this step, whichever list
-// it is in, so the step's sums are final; the list that sets F uses all 64 lanes.  Units are
-// accumulated in a small open-addressing hash table in LDS (at most FAST_T x 64 distinct units per
-// step), lists in query-term order, so a score is the same double sum as on every other path.
-constexpr int HASH_SLOTS = 512;
 constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
-
-// HAS_RANK: url ranks were given (a.url_rank != null); without them a unit's tie-break key is its id
-// waves per SIMD the register budget is held to: what the kernel's LDS allows anyway
-constexpr int hash_waves_per_simd(int cap) { return cap <= 128 ? 4 : cap <= 512 ? 3 : 1; }
-
-template <int CAP, bool HAS_RANK>
-__global__ __launch_bounds__(64, hash_waves_per_simd(CAP)) void k_score_hash(ScoreArgs a) {
-    __shared__ __align__(16) double acc[HASH_SLOTS];
-    __shared__ uint32_t tag[HASH_SLOTS];
-    __shared__ unsigned char cnt[HASH_SLOTS];
-    __shared__ unsigned short used[FAST_T * 64];
-    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP, HAS_RANK>::bytes()];
-
-    const QItem it = a.items[blockIdx.x];
-    const uint32_t lane = lane_id();
-    const uint64_t lt = lanemask_lt();
-    const uint32_t T = it.n_terms;
-    constexpr uint32_t INF = 0xFFFFFFFFu;
-
-    uint32_t my_cur = 0, my_end = 0;
-    double my_idf = 0.0;
-    if (lane < T) {
-        const uint32_t term = a.q_terms[it.term_off + lane];
-        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
-        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
-        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
-        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
-    }
-    // per list: slot index of the current chunk's lane 0, first unconsumed lane of that chunk, end
-    // of the list, and three aligned chunks of units / weights (slots outside [cursor, end) read INF)
-    uint32_t pos[FAST_T], off[FAST_T], end[FAST_T];
-    uint32_t u0[FAST_T], u1[FAST_T], u2[FAST_T], w0[FAST_T], w1[FAST_T], w2[FAST_T];
-    double idf[FAST_T];
-    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& u, uint32_t& w) {
-        const uint32_t i = p + lane;
-        const bool ok = i >= lo && i < end[t];
-        u = ok ? a.post_unit[i] : INF;
-        w = ok ? a.post_w[i] : POST_HOLE;
-    };
-#pragma unroll
-    for (int t = 0; t < FAST_T; ++t) {
-        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
-        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
-        idf[t] = readlane_f64(my_idf, t);
-        pos[t] = cur & ~63u;
-        off[t] = cur & 63u;
-        if (cur >= end[t]) {  // empty list (or t >= T): nothing to read
-            pos[t] = 0;
-            off[t] = 0;
-            end[t] = 0;
-        }
-        load_chunk(t, pos[t], cur, u0[t], w0[t]);
-        load_chunk(t, pos[t] + 64u, cur, u1[t], w1[t]);
-        load_chunk(t, pos[t] + 128u, cur, u2[t], w2[t]);
-    }
-    for (uint32_t x = lane; x < HASH_SLOTS; x += 64) tag[x] = HASH_EMPTY;
-    TopK<CAP, HAS_RANK> tk;
-    tk.init(topk_mem);
-    __builtin_amdgcn_wave_barrier();
-
-    while (true) {
-        // frontier: the smallest last unit of the chunks at hand (INF for a list whose rest is in registers)
-        uint32_t frontier = INF, any = INF;
-#pragma unroll
-        for (int t = 0; t < FAST_T; ++t) {
-            if ((uint32_t)t < T) {
-                any = min(any, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], (int)off[t]));
-                frontier = min(frontier, (uint32_t)__builtin_amdgcn_readlane((int)u0[t], 63));
-            }
-        }
-        if (any == INF) break;  // every list is used up
-
-        uint32_t n_used = 0;
-#pragma unroll
-        for (int t = 0; t < FAST_T; ++t) {
-            if ((uint32_t)t >= T) break;
-            const bool in = lane >= off[t] && u0[t] != INF && u0[t] <= frontier;
-            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-            bool fresh = false;
-            uint32_t h = 0;
-            if (in && w0[t] != POST_HOLE) {  // a hole only moves the cursor
-                const uint32_t u = u0[t];
-                const double v = __dmul_rn(idf[t], (double)w0[t]);
-                h = (u * 2654435761u) >> 23;  // 9 bits: HASH_SLOTS = 512
-                while (true) {
-                    const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, u);
-                    if (old == HASH_EMPTY) {
-                        fresh = true;
-                        break;
-                    }
-                    if (old == u) break;
-                    h = (h + 1u) & (HASH_SLOTS - 1u);
-                }
-                if (fresh) {
-                    acc[h] = v;
-                    cnt[h] = 1;
-                } else {
-                    acc[h] = __dadd_rn(acc[h], v);
-                    cnt[h] = (unsigned char)(cnt[h] + 1);
-                }
-            }
-            const uint64_t fm = __ballot(fresh);
-            if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
-            n_used += (uint32_t)__popcll(fm);
-            off[t] += n_in;
-            if (off[t] >= 64u) {
-                // chunk used up: the next two are in registers already, request the one after them
-                u0[t] = u1[t]; w0[t] = w1[t];
-                u1[t] = u2[t]; w1[t] = w2[t];
-                pos[t] += 64u;
-                off[t] = 0;
-                load_chunk(t, pos[t] + 128u, 0u, u2[t], w2[t]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-
-        // harvest: every unit of this step, 64 per round; the table is left empty again
-        for (uint32_t o0 = 0; o0 < n_used; o0 += 64) {
-            const bool has = o0 + lane < n_used;
-            double s = 0.0;
-            uint32_t h = 0, unit = 0;
-            if (has) {
-                h = used[o0 + lane];
-                s = acc[h];
-                unit = tag[h];
-                tag[h] = HASH_EMPTY;
-            }
-            // most units cannot enter the top k any more: test the score alone before anything else
-            const bool may = has && s >= tk.thr_score;
-            if (__ballot(may)) {
-                uint32_t m = 0, tie = 0;
-                if (may) {
-                    m = cnt[h];
-                    tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
-                }
-                tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    const size_t o = (size_t)it.out_slot * a.k;
-    if (it.direct)
-        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
-                     a.out_count + it.out_slot);
-    else
-        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
-}
 
 // ------------------------------------------------------------------------------------------
 // Stepwise scoring (the default for queries of at most FAST_T lists).
 //
-// As above a step takes, from every list, all slots up to the frontier F.  What differs:
+// A step takes, from every list, all slots up to a frontier F = the smallest "last unit of the chunk in
+// registers" over the lists.  Every posting of a unit <= F is then in this step, whichever list it is in, so
+// the step's sums are final; the list that sets F uses all 64 lanes.
 //  * The accumulators hold the integer weights, one 16-bit field per list (weight + 1, 0 = no
 //    posting).  A list only ever writes its own field, so adding a posting is a plain 2-byte store
 //    (no read-modify-write), the number of matching lists is the number of non-zero fields, and the
@@ -781,7 +643,6 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 
 // Items are grouped by their number of lists: n_by_t[i] items with i + 1 lists for i < FAST_T (stepwise
 // kernels, one instantiation per list count), then n_by_t[FAST_T] items for the general kernel.
-// impl 1 selects the older hashed-accumulator kernel for the first groups (kept for comparison).
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
@@ -794,7 +655,7 @@ static void launch_step(const ScoreArgs& b, hipStream_t st) {
     if (b.url_rank) launch_step_t<T, true>(b, st); else launch_step_t<T, false>(b, st);
 }
 
-void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, int impl, hipStream_t st) {
+void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, hipStream_t st) {
     uint32_t first = 0;
     for (int g = 0; g <= FAST_T; ++g) {
         const uint32_t n = n_by_t[g];
@@ -808,16 +669,6 @@ void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, int impl, hipStrea
             if (a.k <= 64) hipLaunchKernelGGL(k_score<128>, grid, block, 0, st, b);
             else if (a.k <= 256) hipLaunchKernelGGL(k_score<320>, grid, block, 0, st, b);
             else hipLaunchKernelGGL(k_score<2112>, grid, block, 0, st, b);
-        } else if (impl == 1) {
-            if (a.url_rank) {
-                if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, true>), grid, block, 0, st, b);
-                else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, true>), grid, block, 0, st, b);
-                else hipLaunchKernelGGL((k_score_hash<2112, true>), grid, block, 0, st, b);
-            } else {
-                if (a.k <= 64) hipLaunchKernelGGL((k_score_hash<128, false>), grid, block, 0, st, b);
-                else if (a.k <= 256) hipLaunchKernelGGL((k_score_hash<320, false>), grid, block, 0, st, b);
-                else hipLaunchKernelGGL((k_score_hash<2112, false>), grid, block, 0, st, b);
-            }
         } else if (g == 0) launch_step<1>(b, st);
         else if (g == 1) launch_step<2>(b, st);
         else if (g == 2) launch_step<3>(b, st);

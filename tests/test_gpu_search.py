@@ -54,10 +54,10 @@ def test_topk_bit_exact_against_posting_level_oracle(built, k):
 def test_query_edge_cases(built):
     c, orc, ix = built
     V = c["n_terms"]
-    qs = [[], [V + 5], [3, 3, 3], [7, V + 1, 7, 11], list(range(40, 70))]
+    qs = [[], [V + 5], [3, 3, 3], [7, V + 1, 7, 11], list(range(40, 70)), list(range(0, 80)), list(range(100, 330))]
     out = ix.search(qs, 10)
     assert out["count"][0] == 0 and out["count"][1] == 0
-    for qi in (2, 3, 4):
+    for qi in (2, 3, 4, 5, 6):      # the last two: more lists than one wavefront has lanes
         ru, rs, rm = orc.search(np.array(qs[qi], np.uint32), 10, level="csr")
         n = int(out["count"][qi])
         np.testing.assert_array_equal(out["unit"][qi, :n], ru)
@@ -65,7 +65,7 @@ def test_query_edge_cases(built):
         np.testing.assert_array_equal(out["matched"][qi, :n], rm)
     assert out["matched"][2, 0] == 1  # a repeated term counts once
     with pytest.raises(se.Sebm25Error):
-        ix.search([list(range(0, 80))], 10)  # more than 64 distinct matching terms
+        ix.search([list(range(0, 300))], 10)  # more than 255 distinct matching terms
     with pytest.raises(se.Sebm25Error):
         ix.search([[1]], 0)
     with pytest.raises(se.Sebm25Error):
