@@ -843,6 +843,7 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
     const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
     const std::vector<uint32_t>&rp = ix->h_row_ptr, &np = ix->h_news_ptr;
     auto list_len = [&](uint32_t t) -> uint64_t { return news ? rp[t + 1] - np[t] : np[t] - rp[t]; };
+    const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
     size_t nf = 0;
     uint64_t total_len = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
@@ -861,8 +862,27 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
         }
         if (nf - start > MAX_QUERY_TERMS)
             return fail(ix, SEBM25_E_RANGE, "search: more than 255 distinct matching terms in one query");
+        // Stepwise kernels read the lists shortest first and treat the longest one specially; the sum of a
+        // score still runs in the order the caller gave.  order = 2 bits per given position: where that term
+        // now sits (identity for the general kernel, which keeps the given order).
+        uint32_t order = 0xE4u;
+        const size_t nt = nf - start;
+        if (nt >= 2 && nt <= fast_t) {
+            uint32_t given[SCORE_FAST_T], phys_of[SCORE_FAST_T];
+            for (size_t j = 0; j < nt; ++j) given[j] = st.flat[start + j];
+            uint32_t idx[SCORE_FAST_T];
+            for (size_t j = 0; j < nt; ++j) idx[j] = (uint32_t)j;
+            for (size_t a = 1; a < nt; ++a)  // stable insertion sort on the list length
+                for (size_t b = a; b > 0 && list_len(given[idx[b]]) < list_len(given[idx[b - 1]]); --b) std::swap(idx[b], idx[b - 1]);
+            order = 0;
+            for (size_t p = 0; p < nt; ++p) {
+                st.flat[start + p] = given[idx[p]];
+                phys_of[idx[p]] = (uint32_t)p;
+            }
+            for (size_t j = 0; j < nt; ++j) order |= phys_of[j] << (2 * j);
+        }
         st.q_toff[q] = (uint32_t)start;
-        st.q_nt[q] = (uint32_t)(nf - start);
+        st.q_nt[q] = (uint32_t)nt | (order << 8);
         st.q_len[q] = len;
         total_len += len;
     }
@@ -904,7 +924,8 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
             QItem it{};
             it.q = q;
             it.term_off = st.q_toff[q];
-            it.n_terms = st.q_nt[q];
+            it.n_terms = st.q_nt[q] & 0xFFu;
+            it.order = st.q_nt[q] >> 8;
             it.unit_lo = (uint32_t)((uint64_t)n_units * sl / ns);
             it.unit_hi = sl + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (sl + 1) / ns);
             it.direct = ns == 1;

@@ -155,7 +155,7 @@ struct QItem {
     uint32_t unit_lo, unit_hi;
     uint32_t out_slot;  // result list index (direct output row or temporary slice list)
     uint32_t direct;    // 1: writes the final result row
-    uint32_t pad;
+    uint32_t order;     // stepwise kernels: 2 bits per term position as the caller gave it = its place in the list
 };
 struct ScoreArgs {
     const uint32_t* row_ptr;

@@ -427,11 +427,18 @@ struct RegTopK {
     }
 };
 
-constexpr int STEP_SLOTS = 512;
-#ifndef SEBM25_STEP_DEPTH
-#define SEBM25_STEP_DEPTH 3
+#ifndef SEBM25_STEP_BLOCK
+#define SEBM25_STEP_BLOCK 4
 #endif
-constexpr int STEP_DEPTH = SEBM25_STEP_DEPTH;  // chunks of a list held in registers
+#ifndef SEBM25_STEP_BLOCK_MID
+#define SEBM25_STEP_BLOCK_MID 2
+#endif
+#ifndef SEBM25_STEP_WAVES_MID
+#define SEBM25_STEP_WAVES_MID 3
+#endif
+// 64-slot chunks of a list held in registers (and as many in flight): for the variant with the candidates in
+// registers, and for the variants with an LDS candidate buffer (smaller blocks: fewer registers)
+constexpr int STEP_BLOCK = SEBM25_STEP_BLOCK, STEP_BLOCK_MID = SEBM25_STEP_BLOCK_MID, STEP_WAVES_MID = SEBM25_STEP_WAVES_MID;
 
 #ifdef SEBM25_EXP_STATS  // experiment builds only: steps, insert passes, postings inserted, harvest rounds, offers, items
 __device__ unsigned long long g_step_stats[8];
@@ -439,12 +446,24 @@ __device__ unsigned long long g_step_stats[8];
 
 __device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD>
+// Lists sit shortest first (the host orders them); the last one is the longest.
+//  * Every list keeps a block of STEP_BLOCK chunks in registers and has the next block in flight, so a wave has
+//    2 x T x STEP_BLOCK x 512 bytes of loads outstanding while it works.  A step's frontier is the smallest
+//    "last unit of the block" over the lists, so the list that sets it delivers a whole block.
+//  * The longest list is filtered: a unit that only this list holds scores idf_last * w, so its posting is kept
+//    only when that alone reaches the k-th best score held so far (w_min = the smallest such weight, 0 while
+//    fewer than k candidates are held).  Postings of units that a shorter list delivered in this step are found
+//    by probing the table and add their field to the entry.
+template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD, int B, int SLOTS>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) {
     static_assert(T >= 1 && T <= FAST_T, "one 16-bit accumulator field per list");
+    // A step may bring at most LIMIT units into the table (besides up to 63 that wait from earlier steps); a
+    // block-wide step that could bring more is replaced by a chunk-wide one (at most 64 slots per list).
+    constexpr uint32_t STEP_SLOTS = SLOTS, STEP_LIMIT = SLOTS - 64;
+    static_assert((SLOTS & (SLOTS - 1)) == 0 && T * 64 <= (int)STEP_LIMIT, "the table never fills");
     __shared__ uint32_t tag[STEP_SLOTS];
     __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * 4];  // per slot and list: weight in tenths + 1
-    __shared__ unsigned short used[64 * T + 64];
+    __shared__ unsigned short used[STEP_LIMIT + 64];
     __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
 
     const QItem it = a.items[blockIdx.x];
@@ -462,30 +481,51 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
         my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
     }
-    // per list: slot index of the current chunk's lane 0, end of the list, the unit in the current
-    // chunk's last lane, and STEP_DEPTH aligned chunks of units / weights.  A slot outside
-    // [cursor, end) and a slot already used read as INF.
-    uint32_t pos[T], end[T], last[T];
-    uint32_t u[T][STEP_DEPTH], w[T][STEP_DEPTH];
+    // per list: slot index of the current block's first slot, end of the list, the current block (units and
+    // weights of slot pos + 64 j + lane) and the next one.  A slot outside [cursor, end) and a slot already used
+    // read as INF.  clast[t][j]: the unit in the last lane of chunk j as it was loaded.
+    uint32_t pos[T], end[T];
+    uint32_t u[T][B], w[T][B], nu[T][B], nw[T][B], clast[T][B];
     double idf[T];
-    auto load_chunk = [&](int t, uint32_t p, uint32_t lo, uint32_t& uu, uint32_t& ww) {
-        const uint32_t i = p + lane;
-        const bool ok = i >= lo && i < end[t];
-        uu = ok ? a.post_unit[i] : INF;
-        ww = ok ? a.post_w[i] : POST_HOLE;
+    auto load_block = [&](int t, uint32_t p, uint32_t lo, uint32_t (&uu)[B], uint32_t (&ww)[B]) {
+        if (p >= lo && p + 64u * B <= end[t]) {  // inside the list: no masks
+            const uint32_t* pu = a.post_unit + p;
+            const uint32_t* pw = a.post_w + p;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                uu[j] = pu[64u * j + lane];
+                ww[j] = pw[64u * j + lane];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const uint32_t i = p + 64u * (uint32_t)j + lane;
+                const bool ok = i >= lo && i < end[t];
+                uu[j] = ok ? a.post_unit[i] : INF;
+                ww[j] = ok ? a.post_w[i] : POST_HOLE;
+            }
+        }
     };
+    // sh[j] / idf[j]: accumulator field and idf of the term the caller gave at position j
+    uint32_t sh[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const uint32_t p = sfirst((it.order >> (2 * j)) & 3u);
+        sh[j] = 16u * p;
+        idf[j] = readlane_f64(my_idf, (int)p);
+    }
+    const double idf_last = readlane_f64(my_idf, T - 1);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
         end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
-        idf[t] = readlane_f64(my_idf, t);
         pos[t] = cur & ~63u;
         if (cur >= end[t]) {  // empty list: nothing to read
             pos[t] = 0;
             end[t] = 0;
         }
-#pragma unroll
-        for (int d = 0; d < STEP_DEPTH; ++d) load_chunk(t, pos[t] + 64u * (uint32_t)d, cur, u[t][d], w[t][d]);
+        load_block(t, pos[t], cur, u[t], w[t]);
+        load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
     }
     for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS; x += 64) {
         tag[x] = HASH_EMPTY;
@@ -494,67 +534,125 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     TK tk;
     tk.init(topk_mem);
     uint32_t n_used = 0;
+    uint32_t w_min = 0;
+    double thr_seen = tk.thr_score;
+    uint32_t F_prev = 0;
+    bool first_step = true;
 #ifdef SEBM25_EXP_STATS
     uint32_t st_steps = 0, st_ins = 0, st_rounds = 0, st_offers = 0, st_passes = 0;
 #endif
 #pragma unroll
-    for (int t = 0; t < T; ++t) last[t] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][0], 63);
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
     __builtin_amdgcn_wave_barrier();
 
     while (true) {
-        uint32_t F = last[0];
+        uint32_t F = clast[0][B - 1];
 #pragma unroll
-        for (int t = 1; t < T; ++t) F = min(F, last[t]);
-        F = sfirst(F);
-        const bool final_step = F == INF;  // every list is in its last chunk: take what is left
-        const uint32_t Fc = min(F, INF - 1u);
-
+        for (int t = 1; t < T; ++t) F = min(F, clast[t][B - 1]);
+        // how much the block-wide step would bring
+        uint32_t n_in = 0;
+        {
+            const uint32_t Fb = min(F, INF - 1u);
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const bool in = u[t][0] <= Fc;
-            const bool s = in && w[t][0] != POST_HOLE;  // a hole only leaves its chunk
-            const uint64_t sm = __ballot(s);
-#ifdef SEBM25_EXP_STATS
-            st_ins += (uint32_t)__popcll(sm);
-            st_passes += sm ? 1u : 0u;
-            if (t == 0) ++st_steps;
-#endif
-            if (sm) {
-                bool fresh = false;
-                uint32_t h = 0;
-                if (s) {
-                    const uint32_t un = u[t][0];
-                    h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
-                    while (true) {
-                        const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, un);
-                        if (old == HASH_EMPTY) {
-                            fresh = true;
-                            break;
-                        }
-                        if (old == un) break;
-                        h = (h + 1u) & (STEP_SLOTS - 1u);
-                    }
-                    wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][0] + 1u);
-                }
-                const uint64_t fm = __ballot(fresh);
-                if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
-                n_used += (uint32_t)__popcll(fm);
-                __builtin_amdgcn_wave_barrier();
-            }
-            // used slots leave their chunk; a chunk whose last slot is used is replaced by the next one
-            if (last[t] <= Fc) {
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int d = 0; d + 1 < STEP_DEPTH; ++d) {
-                    u[t][d] = u[t][d + 1];
-                    w[t][d] = w[t][d + 1];
-                }
-                pos[t] += 64u;
-                load_chunk(t, pos[t] + 64u * (STEP_DEPTH - 1), 0u, u[t][STEP_DEPTH - 1], w[t][STEP_DEPTH - 1]);
-                last[t] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][0], 63);
-            } else {
-                u[t][0] = in ? INF : u[t][0];
+                for (int j = 0; j < B; ++j)  // of the longest list only what passes its filter (holes count: harmless)
+                    n_in += (uint32_t)__popcll(__ballot(u[t][j] <= Fb && (t < T - 1 || w[t][j] >= w_min)));
+        }
+        if (n_in > STEP_LIMIT) {
+            // chunk-wide step: the frontier is the smallest last unit over every list's first chunk that is not used up
+            F = INF;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                uint32_t c = clast[t][B - 1];
+#pragma unroll
+                for (int j = B - 2; j >= 0; --j) c = (first_step || clast[t][j] > F_prev) ? clast[t][j] : c;
+                F = min(F, c);
             }
         }
+        first_step = false;
+        const bool final_step = F == INF;  // every list is in its last block: take what is left
+        const uint32_t Fc = min(F, INF - 1u);
+        F_prev = Fc;
+
+        bool probe = false;  // the shorter lists brought units into the table in this step
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool advance = clast[t][B - 1] <= Fc;  // the block is used up by this step
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const bool in = u[t][j] <= Fc;
+                if (!__ballot(in)) continue;
+                bool s = in && w[t][j] != POST_HOLE;  // a hole only leaves its chunk
+                if (t == T - 1) {
+                    // the longest list: add to units that are in the table, insert only what could rank alone
+                    bool found = false;
+                    if (probe && __ballot(s)) {
+                        if (s) {
+                            const uint32_t un = u[t][j];
+                            uint32_t h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
+                            while (true) {
+                                const uint32_t tg = tag[h];
+                                if (tg == un) {
+                                    found = true;
+                                    break;
+                                }
+                                if (tg == HASH_EMPTY) break;
+                                h = (h + 1u) & (STEP_SLOTS - 1u);
+                            }
+                            if (found) wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    s = s && !found && w[t][j] >= w_min;
+                }
+                const uint64_t sm = __ballot(s);
+#ifdef SEBM25_EXP_STATS
+                st_ins += (uint32_t)__popcll(sm);
+                st_passes += sm ? 1u : 0u;
+#endif
+                if (sm) {
+                    bool fresh = false;
+                    uint32_t h = 0;
+                    if (s) {
+                        const uint32_t un = u[t][j];
+                        h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
+                        while (true) {
+                            const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, un);
+                            if (old == HASH_EMPTY) {
+                                fresh = true;
+                                break;
+                            }
+                            if (old == un) break;
+                            h = (h + 1u) & (STEP_SLOTS - 1u);
+                        }
+                        wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
+                    }
+                    const uint64_t fm = __ballot(fresh);
+                    if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
+                    n_used += (uint32_t)__popcll(fm);
+                    if (t < T - 1) probe = true;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!advance) u[t][j] = in ? INF : u[t][j];  // used slots leave their chunk
+            }
+            if (advance) {  // the block in flight becomes the current one, the one behind it is requested
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    u[t][j] = nu[t][j];
+                    w[t][j] = nw[t][j];
+                }
+                pos[t] += 64u * B;
+                load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
+#pragma unroll
+                for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
+            }
+        }
+#ifdef SEBM25_EXP_STATS
+        ++st_steps;
+#endif
 
         // harvest 64 units at a time from the back of the list of used slots
         while (n_used >= 64u || (final_step && n_used)) {
@@ -570,10 +668,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 tag[h] = HASH_EMPTY;
                 *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = 0ull;
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const uint32_t ft = (uint32_t)(f >> (16 * t)) & 0xFFFFu;
+                for (int j = 0; j < T; ++j) {  // the order the caller gave the terms in
+                    const uint32_t ft = (uint32_t)(f >> sh[j]) & 0xFFFFu;
                     if (ft) {
-                        const double v = __dmul_rn(idf[t], (double)(ft - 1u));
+                        const double v = __dmul_rn(idf[j], (double)(ft - 1u));
                         s = m ? __dadd_rn(s, v) : v;
                         ++m;
                     }
@@ -593,6 +691,20 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             __builtin_amdgcn_wave_barrier();
         }
         if (final_step) break;
+        if (tk.thr_score != thr_seen) {  // the k-th best score rose: what the longest list must now bring alone
+            thr_seen = tk.thr_score;
+            w_min = 0;
+            if (idf_last > 0.0 && thr_seen > 0.0) {
+                const double x = thr_seen / idf_last;
+                if (x >= 65535.0) {
+                    w_min = 0xFFFFu;  // above every 16-bit weight
+                } else {
+                    w_min = (uint32_t)x;
+                    w_min = w_min > 1u ? w_min - 2u : 0u;
+                    while (__dmul_rn(idf_last, (double)w_min) < thr_seen) ++w_min;  // exact: the product the harvest forms
+                }
+            }
+        }
     }
 #ifdef SEBM25_EXP_STATS
     if (lane == 0) {
@@ -646,9 +758,10 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, 5>), grid, block, 0, st, b);
-    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, 3>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1>), grid, block, 0, st, b);
+    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, 5, STEP_BLOCK, 512>), grid, block, 0, st, b);
+    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
+    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
 }
 template <int T>
 static void launch_step(const ScoreArgs& b, hipStream_t st) {
