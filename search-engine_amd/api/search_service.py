@@ -7,8 +7,10 @@ that changes is where candidate rows come from: instead of `cur.execute(SEARCH_S
 (search_service.py:319-320, :351-352) the rows come from `SearchEngine.score_web/score_news`,
 in the same tuple layout and order.
 
-A process configures the engine once (`configure(engine)`); the GPU call runs in a worker thread
-so the event loop that serves other requests is never blocked (ctypes releases the GIL).
+A process configures the engine once (`configure(engine)`); the engine builds its index on first use
+and can follow the statistics job (`engine.start_auto_refresh`).  Requests that arrive together are
+scored as one batch (`_MicroBatcher`); the GPU call runs in a worker thread, so the event loop that
+serves other requests is never blocked (ctypes releases the GIL).
 """
 from __future__ import annotations
 
@@ -80,9 +82,52 @@ def _iso(v):
     return v.isoformat() if hasattr(v, "isoformat") else str(v)
 
 
+class _MicroBatcher:
+    """Coalesces the scoring calls of coroutines that run at the same time into one batched GPU search
+    (and one metadata statement) per kind.  The reference opens a connection and runs one statement per
+    request (search_service.py:316-320); here a request waits at most `max_wait_s` for company."""
+
+    def __init__(self, service, max_wait_s: float = 0.001, max_batch: int = 256):
+        self._service = service
+        self.max_wait_s = max_wait_s
+        self.max_batch = max_batch
+        self._loop = None
+        self._pending: list = []
+        self._task = None
+        self.batches = 0          # batched engine calls issued (for tests and metrics)
+
+    async def submit(self, kind: str, terms, limit: int):
+        loop = asyncio.get_running_loop()
+        if loop is not self._loop:          # a new event loop (e.g. a new asyncio.run): nothing carries over
+            self._loop, self._pending, self._task = loop, [], None
+        fut = loop.create_future()
+        self._pending.append((kind, list(terms), int(limit), fut))
+        if self._task is None or self._task.done():
+            self._task = loop.create_task(self._drain())
+        return await fut
+
+    async def _drain(self):
+        await asyncio.sleep(self.max_wait_s)
+        while self._pending:
+            batch, self._pending = self._pending[:self.max_batch], self._pending[self.max_batch:]
+            engine = self._service._require_engine()
+            try:
+                self.batches += 1
+                results = await asyncio.to_thread(engine.score_batch, [(k, t, l) for k, t, l, _ in batch])
+            except Exception as e:  # noqa: BLE001 - every waiting request sees the failure, as it would its own
+                for *_, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(e)
+            else:
+                for (*_, fut), res in zip(batch, results):
+                    if not fut.done():
+                        fut.set_result(res)
+
+
 class SearchService:
     def __init__(self, engine=None):
         self.engine = engine
+        self.batcher = _MicroBatcher(self)
 
     # ---- text helpers (search_service.py:150-172)
     def _normalize_text(self, text: str) -> str:
@@ -207,13 +252,12 @@ class SearchService:
         context = self._search_context(q, limit, offset)
         if not context:
             return WebSearchResponse(results=[], count=0)
-        engine = self._require_engine()
-        try:
-            rows = await asyncio.to_thread(engine.score_web, context["query_terms"], context["candidate_limit"])
+        self._require_engine()
+        kind, rows = await self.batcher.submit("web", context["query_terms"], context["candidate_limit"])
+        if kind == "rows":
             ranked = self._rank_web_rows(rows, context=context)
-        except UnicodeError:
-            pairs = await asyncio.to_thread(engine.score_web_pairs, context["query_terms"], context["candidate_limit"])
-            ranked = self._rank_score_only_rows(pairs, context=context)
+        else:   # the row text could not be decoded: score-only rows, reduced ranking (search_service.py:321-338)
+            ranked = self._rank_score_only_rows(rows, context=context)
         page = ranked[offset: offset + limit]
         return WebSearchResponse(results=page, count=max(len(ranked), offset + len(page)))
 
@@ -221,8 +265,8 @@ class SearchService:
         context = self._search_context(q, limit, offset)
         if not context:
             return NewsSearchResponse(results=[], count=0)
-        engine = self._require_engine()
-        rows = await asyncio.to_thread(engine.score_news, context["query_terms"], context["candidate_limit"])
+        self._require_engine()
+        _, rows = await self.batcher.submit("news", context["query_terms"], context["candidate_limit"])
         ranked = self._rank_news_rows(rows, context=context)
         page = ranked[offset: offset + limit]
         return NewsSearchResponse(results=page, count=max(len(ranked), offset + len(page)))

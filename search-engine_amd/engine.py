@@ -4,6 +4,17 @@ the scoring call that stands where the reference executes its search SQL.
 `SearchEngine.score_web / score_news` return rows in exactly the tuple layout the reference's
 statements yield (app/api/search_service.py:36 and :69-88), ordered token_score DESC, url ASC and
 cut at the candidate limit, so the ranking code above them is unchanged.
+
+Lifecycle.  The reference runs the statistics job and the search API as separate processes
+(docker-compose.yml:50,67) that meet in the database: its search statement reads the live `tokens`
+table and the idf values the job last wrote.  Here every process holds its own index, a snapshot of
+`tokens`:
+  * the job's engine: `rebuild()` = export, build, write `term_statistics`;
+  * the API's engine: builds itself on first use (`ensure_ready`), scores with the idf values of the
+    table (`idf_source="table"`, i.e. COALESCE(ts.idf, 1.0) as the reference's LEFT JOIN), and
+    `refresh_if_changed()` / `start_auto_refresh(interval_s)` rebuild it when the table's signature
+    changes, i.e. after each run of the job.  Between two refreshes searches see the snapshot: rows the
+    crawler wrote since are not visible (the staleness window is the refresh interval plus one export).
 """
 from __future__ import annotations
 
@@ -12,66 +23,181 @@ import threading
 import numpy as np
 
 from .native import SRC_NEWS, SRC_WEB
-from .store import SqlStore, TokenExport, url_ranks
+from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, url_ranks
+
+
+def _pinned_alloc():
+    """Row arrays in page-locked memory when a GPU is present: the library then copies them at full
+    PCIe rate without staging."""
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+    except Exception:  # noqa: BLE001
+        return None
+    kinds = {np.dtype(np.uint32): torch.int32, np.dtype(np.uint8): torch.uint8}
+
+    def alloc(n, dtype):
+        t = torch.empty(max(int(n), 1), dtype=kinds[np.dtype(dtype)], pin_memory=True)
+        return t.numpy().view(dtype)[:n]
+
+    return alloc
 
 
 class SearchEngine:
     """One index + the dictionaries needed to talk in term strings and urls.
 
     index_factory() must return an object with the methods of native.Index (build, stats,
-    set_idf, set_url_rank, search).  The default creates a native.Index on GPU `device`."""
+    set_idf, set_url_rank, search).  The default creates a native.Index on GPU `device`.
+    idf_source: "fresh" scores with the idf of this build; "table" with the values stored in
+    term_statistics (1.0 for a term without a row)."""
 
-    def __init__(self, store: SqlStore, device: int = 0, index_factory=None, collation_key=None):
+    def __init__(self, store: SqlStore, device: int = 0, index_factory=None, collation_key=None, idf_source: str = "fresh"):
+        if idf_source not in ("fresh", "table"):
+            raise ValueError("idf_source must be 'fresh' or 'table'")
         self.store = store
         self._factory = index_factory or (lambda: _native_index(device))
+        self._native = index_factory is None
         self._collation_key = collation_key
-        self._lock = threading.Lock()    # one index handle serves one call at a time
+        self._lock = threading.Lock()        # one index handle serves one call at a time
+        self._build_lock = threading.Lock()  # one rebuild at a time
+        self._ready_lock = threading.Lock()
+        self.idf_source = idf_source
         self.index = None
         self.export: TokenExport | None = None
+        self.table_version = None
+        self._refresher = None
+        self._stop = threading.Event()
 
     # ---- the statistics job: replaces the SQL of app/batch/bm25_stats.py:9-27
     def rebuild(self, write_back: bool = True) -> dict:
-        ex = self.store.export_tokens()
-        ix = self._factory()
-        ix.build(ex.term_id, ex.unit_id, ex.tf, ex.meta, ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count,
-                 ex.doc_flags, unit_major=ex.unit_major)
-        st = ix.stats()
-        if ex.n_docs:
-            ix.set_url_rank(SRC_WEB, url_ranks(ex.doc_urls, self._collation_key))
-        # articles are exported in url order already: their index is their rank
-        if write_back:
-            self.store.write_term_statistics(ex.terms, st["df"], st["idf"], st["avgdl"], st["term_rows"])
-        with self._lock:
-            old, self.index, self.export = self.index, ix, ex    # readers see the old index or the new one
-        if old is not None and hasattr(old, "close"):
-            old.close()
-        return st
+        with self._build_lock:
+            ex = self.store.export_tokens(alloc=_pinned_alloc() if self._native else None)
+            ix = self._factory()
+            ix.build(ex.term_id, ex.unit_id, ex.tf, ex.meta, ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count,
+                     ex.doc_flags, unit_major=ex.unit_major)
+            st = ix.stats()
+            if ex.n_docs:
+                ix.set_url_rank(SRC_WEB, url_ranks(ex.doc_urls, self._collation_key))
+            # articles are exported in url order already: their index is their rank
+            if write_back:
+                self.store.write_term_statistics(ex.terms, st["df"], st["idf"], st["avgdl"], st["term_rows"],
+                                                 ex.extra_term_rows)
+            version = self.store.term_statistics_version()
+            if self.idf_source == "table":
+                self._apply_table_idf(ix, ex)
+            with self._lock:
+                old, self.index, self.export = self.index, ix, ex    # readers see the old index or the new one
+                self.table_version = version
+            if old is not None and hasattr(old, "close"):
+                old.close()
+            return st
 
-    def load_idf_from_table(self):
-        """Scores with the idf values currently stored in term_statistics (COALESCE(ts.idf, 1.0)
-        for terms without a row), as the reference's LEFT JOIN does between two runs of the job."""
-        ex = self.export
+    def refresh(self) -> dict:
+        """Rebuilds this process's index from the database without touching term_statistics."""
+        return self.rebuild(write_back=False)
+
+    def ensure_ready(self):
+        """Builds the index on first use (a process that only searches never runs the job)."""
+        if self.index is None:
+            with self._ready_lock:
+                if self.index is None:
+                    self.refresh()
+
+    def refresh_if_changed(self) -> bool:
+        """Rebuilds when term_statistics differs from what this index was built beside (the job ran)."""
+        if self.index is not None and self.store.term_statistics_version() == self.table_version:
+            return False
+        self.refresh()
+        return True
+
+    def start_auto_refresh(self, interval_s: float = 30.0):
+        """Polls term_statistics every interval_s seconds in a daemon thread and rebuilds on change."""
+        if self._refresher is not None:
+            return
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.wait(interval_s):
+                try:
+                    self.refresh_if_changed()
+                except Exception:  # noqa: BLE001 - keep serving the old snapshot; the next tick tries again
+                    pass
+
+        self._refresher = threading.Thread(target=loop, name="sebm25-refresh", daemon=True)
+        self._refresher.start()
+
+    def stop_auto_refresh(self):
+        self._stop.set()
+        if self._refresher is not None:
+            self._refresher.join(timeout=5)
+            self._refresher = None
+
+    def _apply_table_idf(self, ix, ex):
         table = self.store.read_term_statistics()
         idf = np.ones(ex.n_terms, np.float64)
         present = np.zeros(ex.n_terms, np.uint8)
         for t, term in enumerate(ex.terms):
-            if term in table:
-                idf[t], present[t] = table[term], 1
+            v = table.get(term)
+            if v is not None:
+                idf[t], present[t] = v, 1
+        ix.set_idf(idf, present)
+
+    def load_idf_from_table(self):
+        """Scores with the idf values currently stored in term_statistics (COALESCE(ts.idf, 1.0)
+        for terms without a row), as the reference's LEFT JOIN does between two runs of the job."""
         with self._lock:
-            self.index.set_idf(idf, present)
+            self._apply_table_idf(self.index, self.export)
 
     # ---- the scoring call: replaces cur.execute(SEARCH_SQL / NEWS_SEARCH_SQL, (terms, limit))
-    def _score(self, source: int, terms, limit: int):
-        if self.index is None:
-            raise RuntimeError("SearchEngine.rebuild() has not run yet")
+    def _score_many(self, source: int, requests):
+        """requests: [(terms, limit)] -> (export, [(unit, score, matched)]) from ONE batched search."""
+        self.ensure_ready()
         with self._lock:
             ex, ix = self.export, self.index
-            ids = [ex.term_index[t] for t in terms if t in ex.term_index]    # unknown terms match nothing
-            if not ids:
-                return ex, np.zeros(0, np.uint32), np.zeros(0), np.zeros(0, np.uint32)
-            out = ix.search([ids], int(limit), source=source)
-        n = int(out["count"][0])
-        return ex, out["unit"][0, :n], out["score"][0, :n], out["matched"][0, :n]
+            queries = [[ex.term_index[t] for t in terms if t in ex.term_index] for terms, _ in requests]
+            kmax = max([int(limit) for _, limit in requests] + [1])
+            live = [i for i, q in enumerate(queries) if q]      # unknown terms match nothing
+            out = ix.search([queries[i] for i in live], kmax, source=source) if live else None
+        res = [(np.zeros(0, np.uint32), np.zeros(0), np.zeros(0, np.uint32))] * len(requests)
+        for j, i in enumerate(live):
+            # a result list cut at a smaller limit is a prefix of the list cut at a larger one
+            n = min(int(out["count"][j]), int(requests[i][1]))
+            res[i] = (out["unit"][j, :n], out["score"][j, :n], out["matched"][j, :n])
+        return ex, res
+
+    def _score(self, source: int, terms, limit: int):
+        ex, res = self._score_many(source, [(terms, limit)])
+        return (ex,) + res[0]
+
+    def score_batch(self, requests) -> list:
+        """requests: [(kind, terms, limit)], kind 'web' | 'news'.  One batched GPU search per kind and one
+        metadata statement per kind for the whole batch.  -> per request ('rows', rows) in the layout of
+        score_web / score_news, or ('pairs', [(token_score, matched_terms)]) for web requests when the row
+        text cannot be decoded (the reference's fallback, search_service.py:321-338)."""
+        out = [None] * len(requests)
+        for kind, source in (("web", SRC_WEB), ("news", SRC_NEWS)):
+            idx = [i for i, r in enumerate(requests) if r[0] == kind]
+            if not idx:
+                continue
+            ex, res = self._score_many(source, [(requests[i][1], requests[i][2]) for i in idx])
+            if kind == "web":
+                ids = [[int(ex.doc_ids[u]) for u in unit] for unit, _, _ in res]
+                try:
+                    meta = self.store.web_rows([i for row in ids for i in row])
+                except TEXT_DECODE_ERRORS:
+                    for i, (_, score, matched) in zip(idx, res):
+                        out[i] = ("pairs", [(float(s), int(m)) for s, m in zip(score, matched)])
+                    continue
+                for i, row_ids, (_, score, matched) in zip(idx, ids, res):
+                    out[i] = ("rows", [meta[d] + (float(s), int(m)) for d, s, m in zip(row_ids, score, matched) if d in meta])
+            else:
+                urls = [[ex.article_urls[u] for u in unit] for unit, _, _ in res]
+                meta = self.store.news_rows([u for row in urls for u in row])
+                for i, row_urls, (_, score, matched) in zip(idx, urls, res):
+                    out[i] = ("rows", [meta[u] + (float(s), int(m)) for u, s, m in zip(row_urls, score, matched) if u in meta])
+        return out
 
     def score_web(self, terms, limit: int) -> list:
         """[(title, description, url, token_score, matched_terms)] (search_service.py:36)."""

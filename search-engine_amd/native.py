@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+_HERE = os.path.dirname(os.path.realpath(__file__))
 LIB_PATH = os.environ.get("SEBM25_LIB") or os.path.join(_HERE, "lib", "libsebm25.so")
 
 SRC_WEB, SRC_NEWS = 1, 2

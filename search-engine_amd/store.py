@@ -1,21 +1,43 @@
 """Export / import between the reference's SQL tables and the arrays the GPU index takes.
 
 Input side: the `tokens` table (alembic/versions/0001_initial_schema.py:65-74 +
-0007_unify_news_tokens.py:19-27), `documents.word_count/status` (0001:42,45) and the url columns
+0007_unify_news_tokens.py:19-27; writers app/crawler/worker.py:229-239 and
+app/batch/news_fetcher.py:303-311), `documents.word_count/status` (0001:42,45) and the url columns
 used for ORDER BY ... url ASC.  Output side: the `term_statistics` table (0001:110-115), replaced
 in one transaction exactly as app/batch/bm25_stats.py:15-27 does through app/common/db.py:27, so
 unmodified readers keep working.
 
-`SqlStore` speaks DB-API 2.0 and is exercised here with the stdlib sqlite3 module; the same
-statements run on PostgreSQL through psycopg (`SqlStore.from_postgres_env`, which needs psycopg
-and is therefore import-gated: it is absent from the build container).
+The export is one snapshot (a single REPEATABLE READ / deferred transaction, so rows the crawler
+commits meanwhile are either all seen or not at all), streamed in chunks and converted column by
+column with numpy: no per-row Python work.  The term dictionary is derived from the streamed rows
+themselves.  Rows come in heap order (no ORDER BY: sorting 1e8+ rows inside the database costs far
+more than the two extra radix passes the GPU needs for rows that are not unit-major).
+
+`SqlStore` speaks DB-API 2.0 and is exercised here with the stdlib sqlite3 module; on PostgreSQL
+(psycopg 3, `SqlStore.from_postgres_env`, import-gated: psycopg is absent from the build container)
+the rows leave through `COPY (SELECT ...) TO STDOUT` and `term_statistics` is refilled through
+`COPY ... FROM STDIN`.
 """
 from __future__ import annotations
 
+import io
+import itertools
 import os
 from dataclasses import dataclass, field
 
 import numpy as np
+
+TOKEN_COLUMNS = ("COALESCE(doc_id, -1), term, field, frequency, COALESCE(article_url, ''), COALESCE(source_type, 1)")
+
+# what a failed text decode of row metadata looks like: the reference falls back to a statement without
+# text columns on psycopg's CharacterNotInRepertoire (app/api/search_service.py:321)
+TEXT_DECODE_ERRORS: tuple = (UnicodeError,)
+try:  # pragma: no cover - psycopg is not in the build container
+    import psycopg.errors as _pg_errors  # type: ignore
+
+    TEXT_DECODE_ERRORS = (UnicodeError, _pg_errors.CharacterNotInRepertoire)
+except Exception:  # noqa: BLE001
+    pass
 
 
 @dataclass
@@ -29,10 +51,13 @@ class TokenExport:
     doc_ids: np.ndarray      # int64[n_docs]  dense doc index -> documents.id
     word_count: np.ndarray   # uint32[n_docs]
     doc_flags: np.ndarray    # uint8[n_docs]  1 = status 'done', 2 = word_count IS NULL
-    doc_urls: list           # dense doc index -> url
+    doc_urls: list           # dense doc index -> url (None for a doc id that only `tokens` knows)
     article_urls: list       # article index -> url
     unit_major: bool = True
     term_index: dict = field(default_factory=dict)
+    # rows that reach no unit (a news row whose article is gone): the statistics job still groups them by
+    # term (bm25_stats.py:23-24 reads `tokens` alone), so their terms get a term_statistics row
+    extra_term_rows: np.ndarray | None = None
 
     @property
     def n_terms(self):
@@ -49,19 +74,173 @@ class TokenExport:
 
 def url_ranks(urls, key=None) -> np.ndarray:
     """Rank of each url in ascending order (the GPU's tie-break key).  `key` can reproduce a
-    database collation; the default is code-point order (PostgreSQL "C" collation)."""
-    order = sorted(range(len(urls)), key=(lambda i: key(urls[i])) if key else (lambda i: urls[i]))
+    database collation; the default is code-point order (PostgreSQL "C" collation).  A unit without
+    a url (None) ranks last."""
+    urls = ["\U0010ffff" if u is None else u for u in urls]
+    if key is None:
+        order = np.argsort(np.array(urls, dtype="U"), kind="stable") if urls else np.zeros(0, np.int64)
+    else:
+        order = np.asarray(sorted(range(len(urls)), key=lambda i: key(urls[i])), np.int64)
     rank = np.empty(len(urls), np.uint32)
-    rank[np.asarray(order, np.int64)] = np.arange(len(urls), dtype=np.uint32)
+    rank[order] = np.arange(len(urls), dtype=np.uint32)
     return rank
 
 
-class SqlStore:
-    """DB-API access to the reference's tables.  `paramstyle`: '?' (sqlite3) or '%s' (psycopg)."""
+def _parse_copy_text(buf: bytes):
+    """Columns of a block of `COPY ... TO STDOUT` text-format lines (tab-separated, one row per line)."""
+    import pandas as pd
 
-    def __init__(self, connect, paramstyle="?"):
+    df = pd.read_csv(io.BytesIO(buf), sep="\t", header=None, quoting=3, na_filter=False, engine="c",
+                     dtype={0: np.int64, 1: str, 2: np.int64, 3: np.int64, 4: str, 5: np.int64}, encoding="utf-8")
+    urls = df[4].to_numpy(dtype=object)
+    if len(urls) and any("\\" in u for u in set(urls.tolist())):    # COPY escapes backslash, tab, newline
+        esc = {"\\\\": "\\", "\\t": "\t", "\\n": "\n", "\\r": "\r"}
+        import re
+
+        pat = re.compile(r"\\[\\tnr]")
+        urls = np.array([pat.sub(lambda m: esc[m.group(0)], u) for u in urls.tolist()], dtype=object)
+    return (df[0].to_numpy(), df[1].to_numpy(dtype=object), df[2].to_numpy(), df[3].to_numpy(), urls, df[5].to_numpy())
+
+
+def _factorize(strings):
+    """-> (codes int64[n], distinct strings as a list): hash-based, one pass, no sort."""
+    import pandas as pd
+
+    codes, uniq = pd.factorize(np.asarray(strings, dtype=object))
+    return codes.astype(np.int64), uniq.tolist()
+
+
+class _Assembler:
+    """Turns streamed column chunks into the arrays of a TokenExport."""
+
+    def __init__(self, doc_ids: np.ndarray, art_index: dict):
+        self.doc_ids = doc_ids
+        self.art_index = art_index
+        self.term_index: dict = {}
+        self.parts: list = []            # (term_id, unit, tf, meta)
+        self.unknown_docs: list = []     # int64 arrays of doc ids that `documents` does not hold
+        self.orphan_terms: list = []     # term ids of rows without a unit
+        self.rows_in = 0
+
+    def add(self, doc_id, term, fld, freq, art, st):
+        n = len(doc_id)
+        if n == 0:
+            return
+        self.rows_in += n
+        doc_id = np.asarray(doc_id, np.int64)
+        st = np.asarray(st, np.int64)
+        # ---- terms: unique strings of the chunk, then one dictionary access per distinct term
+        inv, uniq = _factorize(term)
+        ti = self.term_index
+        ids = np.fromiter((ti.setdefault(t, len(ti)) for t in uniq), np.int64, len(uniq))
+        term_id = ids[inv]
+        news = st == 2
+        unit = np.zeros(n, np.int64)
+        keep = np.ones(n, bool)
+        # ---- web rows: position of documents.id in the sorted id column; ids only `tokens` knows are kept
+        # apart and given a (not 'done') doc entry at the end, so COUNT(DISTINCT doc_id) still sees them
+        web = ~news
+        if web.any():
+            d = doc_id[web]
+            pos = np.searchsorted(self.doc_ids, d)
+            pos_c = np.minimum(pos, max(len(self.doc_ids) - 1, 0))
+            known = (self.doc_ids[pos_c] == d) if len(self.doc_ids) else np.zeros(len(d), bool)
+            u = np.where(known, pos_c, -1 - d)          # unknown: encoded doc id, resolved in finish()
+            null_doc = d < 0                            # a web row with NULL doc_id matches nothing and counts nowhere
+            unit[web] = u
+            if (~known & ~null_doc).any():
+                self.unknown_docs.append(np.unique(d[~known & ~null_doc]))
+            if null_doc.any():
+                k = keep[web]
+                k[null_doc] = False
+                keep[web] = k
+                self.orphan_terms.append(term_id[web][null_doc])
+        # ---- news rows: article index by url
+        if news.any():
+            ia, ua = _factorize(np.asarray(art, dtype=object)[news])
+            ai = self.art_index
+            amap = np.fromiter((ai.get(x, -1) for x in ua), np.int64, len(ua))
+            a_unit = amap[ia]
+            unit[news] = a_unit
+            gone = a_unit < 0                           # JOIN news_articles drops it (search_service.py:90)
+            if gone.any():
+                k = keep[news]
+                k[gone] = False
+                keep[news] = k
+                self.orphan_terms.append(term_id[news][gone])
+        tf = np.maximum(np.asarray(freq, np.int64), 0)
+        meta = (np.where(news, 2, 1) | ((np.asarray(fld, np.int64) & 63) << 2)).astype(np.uint8)
+        if not keep.all():
+            term_id, unit, tf, meta = term_id[keep], unit[keep], tf[keep], meta[keep]
+        self.parts.append((term_id, unit, tf.astype(np.uint32), meta))
+
+    def finish(self, docs_word_count, docs_flags, doc_urls, article_urls, alloc) -> TokenExport:
+        R = sum(len(p[0]) for p in self.parts)
+        term_id = alloc(R, np.uint32)
+        unit_id = alloc(R, np.uint32)
+        tf = alloc(R, np.uint32)
+        meta = alloc(R, np.uint8)
+        # final term ids: rank of the term among the distinct terms (deterministic whatever the row order)
+        terms_seen = list(self.term_index)
+        order = np.argsort(np.array(terms_seen, dtype="U"), kind="stable") if terms_seen else np.zeros(0, np.int64)
+        rank = np.empty(len(terms_seen), np.int64)
+        rank[order] = np.arange(len(terms_seen))
+        terms = [terms_seen[i] for i in order.tolist()]
+        doc_ids, word_count, doc_flags = self.doc_ids, docs_word_count, docs_flags
+        remap = None
+        if self.unknown_docs:
+            extra = np.unique(np.concatenate(self.unknown_docs))
+            all_ids = np.union1d(doc_ids, extra)
+            old_pos = np.searchsorted(all_ids, doc_ids)
+            wc2 = np.zeros(len(all_ids), np.uint32)
+            fl2 = np.zeros(len(all_ids), np.uint8)      # not 'done': counts in df, never scored, not in N
+            wc2[old_pos], fl2[old_pos] = word_count, doc_flags
+            urls2 = [None] * len(all_ids)
+            for i, p in enumerate(old_pos.tolist()):
+                urls2[p] = doc_urls[i]
+            remap = (old_pos, all_ids)
+            doc_ids, word_count, doc_flags, doc_urls = all_ids, wc2, fl2, urls2
+        o = 0
+        ordered = True
+        last_key = -1
+        for t_id, unit, tf_c, meta_c in self.parts:
+            n = len(t_id)
+            if n == 0:
+                continue
+            if remap is not None:
+                web = (meta_c & 3) == 1
+                uw = unit[web]
+                known = uw >= 0
+                uw2 = np.empty(len(uw), np.int64)
+                uw2[known] = remap[0][uw[known]]
+                uw2[~known] = np.searchsorted(remap[1], -1 - uw[~known])
+                unit = unit.copy()
+                unit[web] = uw2
+            term_id[o:o + n] = rank[t_id]
+            unit_id[o:o + n] = unit
+            tf[o:o + n] = tf_c
+            meta[o:o + n] = meta_c
+            if ordered:
+                key = ((meta_c & 3).astype(np.int64) << 32) | unit
+                ordered = bool(key[0] >= last_key and (np.diff(key) >= 0).all())
+                last_key = int(key[-1])
+            o += n
+        extra_rows = None
+        if self.orphan_terms:
+            extra_rows = np.bincount(rank[np.concatenate(self.orphan_terms)], minlength=max(len(terms), 1)).astype(np.int64)
+        return TokenExport(term_id, unit_id, tf, meta, terms, doc_ids, word_count, doc_flags, list(doc_urls),
+                           list(article_urls), ordered, {t: i for i, t in enumerate(terms)}, extra_rows)
+
+
+class SqlStore:
+    """DB-API access to the reference's tables.  `paramstyle`: '?' (sqlite3) or '%s' (psycopg, which also
+    selects the PostgreSQL forms: REPEATABLE READ snapshot, COPY out / in, TRUNCATE)."""
+
+    def __init__(self, connect, paramstyle="?", chunk_rows: int = 1 << 20):
         self._connect = connect
         self._p = paramstyle
+        self.postgres = paramstyle == "%s"
+        self.chunk_rows = chunk_rows
 
     @classmethod
     def from_postgres_env(cls):
@@ -76,66 +255,143 @@ class SqlStore:
         return cls(lambda: psycopg.connect(info), "%s")
 
     # ---- export
-    def export_tokens(self) -> TokenExport:
+    def _begin_snapshot(self, cur):
+        if self.postgres:
+            # must be the first statement of the transaction psycopg opens implicitly
+            cur.execute("SET TRANSACTION ISOLATION LEVEL REPEATABLE READ, READ ONLY")
+        else:
+            try:
+                cur.execute("BEGIN")
+            except Exception:  # noqa: BLE001 - a driver that already opened the transaction
+                pass
+
+    def _token_chunks(self, conn, cur, where="", params=()):
+        """Yields (doc_id, term, field, frequency, article_url, source_type) column chunks in heap order."""
+        sql = f"SELECT {TOKEN_COLUMNS} FROM tokens{where}"
+        if self.postgres and hasattr(cur, "copy") and not params:
+            yield from self._copy_chunks(cur, sql)
+            return
+        cur.execute(sql, tuple(params))
+        while True:
+            rows = cur.fetchmany(self.chunk_rows)
+            if not rows:
+                return
+            a = np.array(rows, dtype=object)      # one pass over the driver's tuples; columns are views
+            yield (a[:, 0].astype(np.int64), a[:, 1], a[:, 2].astype(np.int64), a[:, 3].astype(np.int64), a[:, 4],
+                   a[:, 5].astype(np.int64))
+
+    def _copy_chunks(self, cur, sql, block_bytes: int = 64 << 20):
+        pend = []
+        size = 0
+        with cur.copy(f"COPY ({sql}) TO STDOUT") as cp:
+            for data in cp:
+                b = bytes(data)
+                pend.append(b)
+                size += len(b)
+                if size >= block_bytes:
+                    buf = b"".join(pend)
+                    cut = buf.rfind(b"\n") + 1
+                    if cut:
+                        yield _parse_copy_text(buf[:cut])
+                    pend, size = [buf[cut:]], len(buf) - cut
+        buf = b"".join(pend)
+        if buf:
+            yield _parse_copy_text(buf)
+
+    def export_tokens(self, alloc=None) -> TokenExport:
+        """The whole `tokens` table + the document columns the job reads, as one snapshot.
+        `alloc(n, dtype)` supplies the four row arrays (e.g. pinned host memory); default numpy."""
+        alloc = alloc or (lambda n, dt: np.empty(n, dt))
         conn = self._connect()
         try:
             cur = conn.cursor()
+            self._begin_snapshot(cur)
             cur.execute("SELECT id, url, word_count, status FROM documents ORDER BY id")
             docs = cur.fetchall()
-            doc_ids = np.array([d[0] for d in docs], np.int64)
-            doc_index = {int(d[0]): i for i, d in enumerate(docs)}
-            word_count = np.array([d[2] or 0 for d in docs], np.uint32)
-            doc_flags = np.array([(1 if str(d[3]) == "done" else 0) | (2 if d[2] is None else 0) for d in docs], np.uint8)
+            dc = list(zip(*docs)) if docs else [(), (), (), ()]
+            doc_ids = np.array(dc[0], np.int64)
+            wc_null = np.fromiter((w is None for w in dc[2]), bool, len(docs))
+            word_count = np.fromiter((w or 0 for w in dc[2]), np.int64, len(docs)).astype(np.uint32)
+            done = np.fromiter((str(s) == "done" for s in dc[3]), bool, len(docs))
+            doc_flags = (done.astype(np.uint8) | (wc_null.astype(np.uint8) << 1)).astype(np.uint8)
             cur.execute("SELECT url FROM news_articles ORDER BY url")
             article_urls = [r[0] for r in cur.fetchall()]
-            art_index = {u: i for i, u in enumerate(article_urls)}
-            cur.execute("SELECT DISTINCT term FROM tokens ORDER BY term")
-            terms = [r[0] for r in cur.fetchall()]
-            term_index = {t: i for i, t in enumerate(terms)}
-            # unit-major order lets the build sort on term alone: web rows by doc, then news rows
-            cur.execute("SELECT doc_id, term, field, frequency, article_url, source_type FROM tokens "
-                        "ORDER BY source_type, doc_id, article_url")
-            rows = cur.fetchall()
+            asm = _Assembler(doc_ids, {u: i for i, u in enumerate(article_urls)})
+            for chunk in self._token_chunks(conn, cur):
+                asm.add(*chunk)
+            ex = asm.finish(word_count, doc_flags, list(dc[1]), article_urls, alloc)
         finally:
+            try:
+                conn.rollback()
+            except Exception:  # noqa: BLE001
+                pass
             conn.close()
-        n = len(rows)
-        term_id = np.empty(n, np.uint32)
-        unit_id = np.empty(n, np.uint32)
-        tf = np.empty(n, np.uint32)
-        meta = np.empty(n, np.uint8)
-        keep = np.ones(n, bool)
-        for i, (doc_id, term, fld, freq, art, st) in enumerate(rows):
-            term_id[i] = term_index[term]
-            tf[i] = max(int(freq), 0)
-            st = int(st or 1)
-            meta[i] = st | ((int(fld) & 63) << 2)
-            if st == 2:
-                if art in art_index:
-                    unit_id[i] = art_index[art]
-                else:
-                    keep[i] = False          # JOIN news_articles drops it (search_service.py:90)
-            elif doc_id is not None and int(doc_id) in doc_index:
-                unit_id[i] = doc_index[int(doc_id)]
-            else:
-                keep[i] = False
-        if not keep.all():
-            term_id, unit_id, tf, meta = term_id[keep], unit_id[keep], tf[keep], meta[keep]
-        key = ((meta & 3).astype(np.int64) << 32) | unit_id
-        return TokenExport(term_id, unit_id, tf, meta, terms, doc_ids, word_count, doc_flags,
-                           [d[1] for d in docs], article_urls, bool((np.diff(key) >= 0).all()), term_index)
+        return ex
 
-    # ---- write back
-    def write_term_statistics(self, terms, df, idf, avgdl, term_rows) -> int:
-        """TRUNCATE + INSERT in one transaction: readers see the old table or the new one."""
+    def export_units(self, ex: TokenExport, doc_ids=(), article_urls=()):
+        """The current rows of a few web docs / articles (for an incremental update): -> dict with
+        term strings and the raw columns, read in one snapshot."""
+        out = dict(doc_rows=[], article_rows=[], docs={}, articles=set())
         conn = self._connect()
         try:
             cur = conn.cursor()
-            cur.execute("DELETE FROM term_statistics")
+            self._begin_snapshot(cur)
             p = self._p
-            rows = [(terms[t], int(df[t]), float(idf[t]), float(avgdl)) for t in range(len(terms)) if term_rows[t] > 0]
-            cur.executemany(f"INSERT INTO term_statistics(term, doc_frequency, idf, avg_doc_len) VALUES ({p},{p},{p},{p})", rows)
+            doc_ids = [int(d) for d in doc_ids]
+            article_urls = list(article_urls)
+            for i in range(0, len(doc_ids), 500):
+                part = doc_ids[i:i + 500]
+                ph = ",".join([p] * len(part))
+                cur.execute(f"SELECT id, url, word_count, status FROM documents WHERE id IN ({ph})", part)
+                for r in cur.fetchall():
+                    out["docs"][int(r[0])] = (r[1], r[2], str(r[3]))
+                cur.execute(f"SELECT doc_id, term, field, frequency FROM tokens WHERE doc_id IN ({ph})", part)
+                out["doc_rows"].extend(cur.fetchall())
+            for i in range(0, len(article_urls), 500):
+                part = article_urls[i:i + 500]
+                ph = ",".join([p] * len(part))
+                cur.execute(f"SELECT url FROM news_articles WHERE url IN ({ph})", part)
+                out["articles"].update(r[0] for r in cur.fetchall())
+                cur.execute(f"SELECT article_url, term, field, frequency FROM tokens WHERE source_type = 2 AND article_url IN ({ph})", part)
+                out["article_rows"].extend(cur.fetchall())
+        finally:
+            try:
+                conn.rollback()
+            except Exception:  # noqa: BLE001
+                pass
+            conn.close()
+        return out
+
+    # ---- write back
+    def write_term_statistics(self, terms, df, idf, avgdl, term_rows, extra_term_rows=None) -> int:
+        """TRUNCATE + INSERT in one transaction: readers see the old table or the new one
+        (bm25_stats.py:15-27 + db.py:27).  A row is written for every term that has token rows."""
+        n = len(terms)
+        rows_of = np.asarray(term_rows[:n], np.int64)
+        if extra_term_rows is not None:
+            rows_of = rows_of + np.asarray(extra_term_rows[:n], np.int64)
+        sel = np.nonzero(rows_of > 0)[0]
+        t_sel = [terms[i] for i in sel.tolist()]
+        df_sel = np.asarray(df)[sel].astype(np.int64).tolist()
+        idf_sel = np.asarray(idf, np.float64)[sel].tolist()
+        avgdl = float(avgdl)
+        conn = self._connect()
+        try:
+            cur = conn.cursor()
+            if self.postgres:
+                cur.execute("TRUNCATE term_statistics")
+            else:
+                cur.execute("DELETE FROM term_statistics")
+            if self.postgres and hasattr(cur, "copy"):
+                with cur.copy("COPY term_statistics (term, doc_frequency, idf, avg_doc_len) FROM STDIN") as cp:
+                    for row in zip(t_sel, df_sel, idf_sel, itertools.repeat(avgdl)):
+                        cp.write_row(row)
+            else:
+                p = self._p
+                cur.executemany(f"INSERT INTO term_statistics(term, doc_frequency, idf, avg_doc_len) VALUES ({p},{p},{p},{p})",
+                                zip(t_sel, df_sel, idf_sel, itertools.repeat(avgdl)))
             conn.commit()
-            return len(rows)
+            return len(t_sel)
         except Exception:
             conn.rollback()
             raise
@@ -148,6 +404,18 @@ class SqlStore:
             cur = conn.cursor()
             cur.execute("SELECT term, idf FROM term_statistics")
             return {r[0]: float(r[1]) for r in cur.fetchall()}
+        finally:
+            conn.close()
+
+    def term_statistics_version(self):
+        """A cheap signature of the table that changes whenever the statistics job has replaced it."""
+        conn = self._connect()
+        try:
+            cur = conn.cursor()
+            cur.execute("SELECT COUNT(*), COALESCE(SUM(doc_frequency), 0), COALESCE(MAX(avg_doc_len), 0), "
+                        "COALESCE(SUM(idf), 0) FROM term_statistics")
+            r = cur.fetchone()
+            return tuple(float(x) for x in r)
         finally:
             conn.close()
 
@@ -167,7 +435,7 @@ class SqlStore:
         return self._by_key(sql, urls)
 
     def _by_key(self, sql, keys) -> dict:
-        keys = list(keys)
+        keys = list(dict.fromkeys(keys))
         if not keys:
             return {}
         out = {}

@@ -79,9 +79,14 @@ class OracleBackedIndex:
         self.orc.set_idf(idf, present)
 
     def search(self, queries, k, source=1):
-        u, s, m = self.orc.search(np.asarray(queries[0], np.uint32), k, source=source, url_rank=self.rank[source], level="csr")
-        n = len(u)
-        return dict(unit=u.reshape(1, n), score=s.reshape(1, n), matched=m.reshape(1, n), count=np.array([n]))
+        nq = len(queries)
+        out = dict(unit=np.zeros((nq, k), np.uint32), score=np.zeros((nq, k)), matched=np.zeros((nq, k), np.uint32),
+                   count=np.zeros(nq, np.uint32))
+        for i, q in enumerate(queries):
+            u, s, m = self.orc.search(np.asarray(q, np.uint32), k, source=source, url_rank=self.rank[source], level="csr")
+            n = len(u)
+            out["unit"][i, :n], out["score"][i, :n], out["matched"][i, :n], out["count"][i] = u, s, m, n
+        return out
 
     def close(self):
         pass
@@ -165,7 +170,179 @@ def test_flow_on_gpu(tmp_path):
     engine.load_idf_from_table()               # COALESCE path: same table, same results
     rows = engine.score_web(["radix", "sort"], 50)
     assert rows[0][2] == "https://gpu.example/radix-sort"
+    check_fallback_rows(engine, str(tmp_path / "se.db"))
+    check_concurrent_requests(engine)
     engine.index.close()
+
+
+def check_fallback_rows(engine, path):
+    """The fallback statement's rows (search_service.py:42-66): (token_score, matched_terms) by score, and the
+    reduced ranking the service applies when the row text cannot be decoded (:321-338)."""
+    terms = ["radix", "sort"]
+    pairs = engine.score_web_pairs(terms, 50)
+    db = sqlite3.connect(path)
+    ref = db.execute("""SELECT SUM(t.frequency * COALESCE(ts.idf, 1.0) * CASE t.field WHEN 1 THEN 3.2 WHEN 2 THEN 1.7 ELSE 1.0 END) AS s,
+                               COUNT(DISTINCT t.term) FROM tokens t JOIN documents d ON d.id = t.doc_id
+                        LEFT JOIN term_statistics ts ON ts.term = t.term
+                        WHERE d.status = 'done' AND t.term IN (?, ?) GROUP BY d.id ORDER BY s DESC LIMIT 50""", terms).fetchall()
+    db.close()
+    assert [m for _, m in pairs] == [m for _, m in ref]
+    np.testing.assert_allclose([s for s, _ in pairs], [s for s, _ in ref], rtol=1e-12)
+
+    class Undecodable(type(engine.store)):
+        def web_rows(self, doc_ids):
+            raise UnicodeDecodeError("utf-8", b"\xff", 0, 1, "invalid start byte")
+
+    good = engine.store
+    engine.store = Undecodable(good._connect, good._p)
+    try:
+        svc = ss.SearchService(engine)
+        out = asyncio.run(svc.perform_web_search(q="radix sort", limit=2, offset=0))
+    finally:
+        engine.store = good
+    ctx = svc._search_context("radix sort", 2, 0)
+    expect = svc._rank_score_only_rows(pairs, context=ctx)
+    assert [i.score for i in out.results] == [i.score for i in expect[:2]]
+    assert all(i.url == "" and i.title == "" for i in out.results) and out.count == len(expect)
+
+
+def check_concurrent_requests(engine, n=96):
+    """Many coroutines at once: coalesced into a few batched searches, results identical to serial calls."""
+    svc = ss.SearchService(engine)
+    queries = ["radix sort", "ranking documents", "postgres sorting rows", "bm25", "archive stories", "gpu keys", "the of"]
+
+    async def serial():
+        return [await svc.perform_web_search(q=queries[i % len(queries)], limit=1 + i % 3, offset=i % 2) for i in range(n)] + \
+               [await svc.perform_news_search(q=queries[i % len(queries)]) for i in range(8)]
+
+    async def together():
+        return await asyncio.gather(*[svc.perform_web_search(q=queries[i % len(queries)], limit=1 + i % 3, offset=i % 2) for i in range(n)],
+                                    *[svc.perform_news_search(q=queries[i % len(queries)]) for i in range(8)])
+
+    a = asyncio.run(serial())
+    before = svc.batcher.batches
+    b = asyncio.run(together())
+    assert [r.model_dump() for r in a] == [r.model_dump() for r in b]
+    assert svc.batcher.batches - before <= 2          # ~100 requests, one or two engine calls
+
+
+def test_fallback_rows_and_concurrent_requests_on_cpu_stand_in(tmp_path):
+    engine = run_flow(tmp_path, OracleBackedIndex)
+    check_fallback_rows(engine, str(tmp_path / "se.db"))
+    check_concurrent_requests(engine)
+
+
+def test_job_and_service_in_separate_engines(tmp_path):
+    """The statistics job and the search API are separate processes in the reference (docker-compose.yml:50,67):
+    here two engines over one database.  The service builds itself on first use, scores with the table's idf
+    and follows the job."""
+    path = str(tmp_path / "se.db")
+    make_db(path)
+    store = SqlStore(lambda: sqlite3.connect(path))
+    service_engine = SearchEngine(store, index_factory=OracleBackedIndex, idf_source="table")
+    svc = ss.SearchService(service_engine)
+    # before the job ever ran: no term_statistics rows, every idf is COALESCE(NULL, 1.0)
+    out0 = asyncio.run(svc.perform_web_search(q="radix sort", limit=5))
+    rows0 = service_engine.score_web(["radix", "sort"], 50)
+    assert out0.results and [r[:3] for r in rows0] == [r[:3] for r in sql_reference_rows(path, ["radix", "sort"], 50)]
+    np.testing.assert_allclose([r[3] for r in rows0], [r[3] for r in sql_reference_rows(path, ["radix", "sort"], 50)], rtol=1e-12)
+    job_engine = SearchEngine(store, index_factory=OracleBackedIndex)
+    job_engine.rebuild()                                   # the job process writes the table
+    assert service_engine.refresh_if_changed() is True     # the service notices and rebuilds
+    assert service_engine.refresh_if_changed() is False
+    rows1 = service_engine.score_web(["radix", "sort"], 50)
+    ref1 = sql_reference_rows(path, ["radix", "sort"], 50)
+    assert [r[:3] for r in rows1] == [r[:3] for r in ref1]
+    np.testing.assert_allclose([r[3] for r in rows1], [r[3] for r in ref1], rtol=1e-12)
+    # the crawler adds a page: invisible until the job has run and the service has refreshed
+    db = sqlite3.connect(path)
+    db.execute("INSERT INTO documents VALUES (30,'https://gpu.example/new','Radix radix','', 'radix', 1, 'done')")
+    db.execute("INSERT INTO tokens VALUES (30,'radix',1,2,NULL,1)")
+    db.commit()
+    db.close()
+    assert "https://gpu.example/new" not in [r[2] for r in service_engine.score_web(["radix"], 50)]
+    job_engine.rebuild()
+    service_engine.start_auto_refresh(0.05)
+    import time
+    for _ in range(100):
+        if "https://gpu.example/new" in [r[2] for r in service_engine.score_web(["radix"], 50)]:
+            break
+        time.sleep(0.05)
+    service_engine.stop_auto_refresh()
+    assert [r[:3] for r in service_engine.score_web(["radix"], 50)] == [r[:3] for r in sql_reference_rows(path, ["radix"], 50)]
+
+
+def test_export_matches_row_by_row_conversion_and_copy_text(tmp_path):
+    """The chunked column-wise export equals a plain row-by-row conversion, whatever the chunk size, and the
+    COPY text path (PostgreSQL) parses to the same arrays.  Rows without a unit keep their term's statistics row."""
+    path = str(tmp_path / "se.db")
+    make_db(path)
+    db = sqlite3.connect(path)
+    db.execute("INSERT INTO tokens VALUES (NULL,'ghostterm',4,3,'https://news.example/gone',2)")      # article deleted meanwhile
+    db.execute("INSERT INTO tokens VALUES (99,'phantomdoc',4,1,NULL,1)")                              # doc id only tokens knows
+    db.commit()
+    rows = db.execute("SELECT COALESCE(doc_id,-1), term, field, frequency, COALESCE(article_url,''), COALESCE(source_type,1) FROM tokens").fetchall()
+    db.close()
+    exports = [SqlStore(lambda: sqlite3.connect(path), chunk_rows=c).export_tokens() for c in (7, 1 << 20)]
+
+    class CopyCursor:
+        """Stands in for a psycopg cursor: .copy(sql) yields the rows in COPY text format, in uneven pieces."""
+        def __init__(self, cur):
+            self._cur = cur
+        def execute(self, sql, params=()):
+            if not sql.startswith("SET TRANSACTION"):
+                self._cur.execute(sql.replace("%s", "?"), params)
+        def fetchall(self):
+            return self._cur.fetchall()
+        def copy(self, sql):
+            text = "".join("\t".join(str(x) for x in r) + "\n" for r in rows).encode()
+            class Ctx:
+                def __enter__(s):
+                    return iter([text[:11], text[11:200], text[200:]])
+                def __exit__(s, *a):
+                    return False
+            return Ctx()
+
+    class CopyConn:
+        def __init__(self):
+            self._c = sqlite3.connect(path)
+        def cursor(self):
+            return CopyCursor(self._c.cursor())
+        def rollback(self):
+            self._c.rollback()
+        def close(self):
+            self._c.close()
+
+    exports.append(SqlStore(CopyConn, "%s").export_tokens())
+    a = exports[0]
+    assert "ghostterm" in a.terms and "phantomdoc" in a.terms
+    assert a.extra_term_rows[a.term_index["ghostterm"]] == 1 and a.extra_term_rows.sum() == 1
+    assert 99 in a.doc_ids.tolist() and a.doc_flags[a.doc_ids.tolist().index(99)] == 0
+    for b in exports[1:]:
+        for name in ("term_id", "unit_id", "tf", "meta", "doc_ids", "word_count", "doc_flags", "extra_term_rows"):
+            np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+        assert a.terms == b.terms and a.doc_urls == b.doc_urls and a.article_urls == b.article_urls
+    # row-by-row conversion of the same table
+    term_index = {t: i for i, t in enumerate(sorted({r[1] for r in rows}))}
+    doc_pos = {int(d): i for i, d in enumerate(a.doc_ids.tolist())}
+    art_pos = {u: i for i, u in enumerate(a.article_urls)}
+    want = []
+    for d, t, f, fr, art, st in rows:
+        if st == 2:
+            if art in art_pos:
+                want.append((term_index[t], art_pos[art], fr, 2 | (f << 2)))
+        else:
+            want.append((term_index[t], doc_pos[d], fr, 1 | (f << 2)))
+    got = list(zip(a.term_id.tolist(), a.unit_id.tolist(), a.tf.tolist(), a.meta.tolist()))
+    assert got == want
+    # end to end: the job writes a row for the orphan's term with df = 0, as GROUP BY t.term over `tokens` does
+    store = SqlStore(lambda: sqlite3.connect(path))
+    SearchEngine(store, index_factory=OracleBackedIndex).rebuild()
+    db = sqlite3.connect(path)
+    got = dict(db.execute("SELECT term, doc_frequency FROM term_statistics").fetchall())
+    want_df = dict(db.execute("SELECT term, COUNT(DISTINCT doc_id) FROM tokens GROUP BY term").fetchall())
+    db.close()
+    assert got == want_df and got["ghostterm"] == 0 and got["phantomdoc"] == 1
 
 
 def test_candidate_limit_formula():
