@@ -165,14 +165,44 @@ int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank);
 /* Added to local unit ids in search results (document-sharded indexes). */
 int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base);
 
+/* ---- incremental update: what the reference does row by row in `tokens` --------------------
+ *
+ * The crawler replaces a document by deleting its rows and inserting the new ones
+ * (app/crawler/worker.py:229-239; news: app/batch/news_fetcher.py:303-311), and the statistics job then
+ * recomputes everything from the whole table every BATCH_INTERVAL_S seconds (.env:11,
+ * app/batch/bm25_stats.py:15-27).  sebm25_update brings an index that is already built to the state a
+ * full build of the changed table would give, reading only the rows of the units that changed:
+ *   - `changed_docs` / `changed_articles` list every unit whose rows were replaced, removed or added
+ *     (also a doc whose status changed); all rows the index holds for them are dropped;
+ *   - `rows` holds the rows these units have now, all fields (nothing for a unit that was removed), with
+ *     rows->n_terms / n_docs / n_articles the sizes of the id spaces now (they can only grow) and
+ *     rows->word_count / doc_flags the full per-doc arrays as they are now.  A row of a unit that is
+ *     not listed fails with SEBM25_E_INVALID and leaves the index as it was.
+ * Afterwards df, term_rows, N, avgdl, idf, doc lengths, the postings and every search result equal
+ * those of sebm25_build over the final table, bit for bit.  The new rows are held as a segment of their
+ * own (at most 64 of them; a search scores every segment and merges); sebm25_compact folds all
+ * segments into one.  url ranks must be set again when an update adds units; an idf override
+ * (sebm25_set_idf) is replaced by the recomputed idf.  sebm25_update_local leaves the statistics to a
+ * following sebm25_local_stats / sebm25_finalize (document-sharded indexes), as sebm25_build_local does.
+ */
+int sebm25_update(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* changed_docs, uint32_t n_changed_docs,
+                  const uint32_t* changed_articles, uint32_t n_changed_articles);
+int sebm25_update_local(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* changed_docs, uint32_t n_changed_docs,
+                        const uint32_t* changed_articles, uint32_t n_changed_articles);
+/* Rebuilds one segment from the live rows of all segments, on the device (no rows cross the host).
+ * Results do not change.  The statistics stay finalized. */
+int sebm25_compact(sebm25_index* ix);
+
 /* Sizes of the built index. */
 typedef struct sebm25_index_info {
     uint64_t n_rows;
     uint64_t n_postings;      /* kept postings, web + news */
     uint64_t n_web_postings;
     uint32_t n_terms, n_docs, n_articles;
-    uint32_t term_bits, unit_bits, tf_bits; /* packed sort row layout */
+    uint32_t term_bits, unit_bits, tf_bits; /* packed sort row layout of the base segment */
     uint32_t sort_passes;
+    uint32_t n_segments;      /* 1 + the update segments held since the last build or compaction */
+    uint64_t n_dead_rows;     /* rows of replaced or removed units that the segments still carry */
 } sebm25_index_info;
 int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
 

@@ -34,5 +34,15 @@ async def run() -> None:
     await asyncio.to_thread(_engine.rebuild)
 
 
+async def run_incremental(doc_ids=(), article_urls=()) -> None:
+    """The job for a known set of changes: the documents (documents.id) and news articles (url) the crawler
+    and the news fetcher wrote since the last run.  Same effect on term_statistics and on searches as run(),
+    without reading the whole `tokens` table again."""
+    global _engine
+    if _engine is None:
+        _engine = _default_engine()
+    await asyncio.to_thread(_engine.update, list(doc_ids), list(article_urls))
+
+
 if __name__ == "__main__":
     asyncio.run(run())

@@ -60,6 +60,19 @@ struct sebm25_index {
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
     uint32_t* post_unit = nullptr;
     uint32_t* post_w = nullptr;  // weights in tenths
+    const uint64_t* sorted_rows = nullptr;  // the sorted packed rows this segment was built from (read again by updates)
+    const uint32_t* wc_dev = nullptr;       // device views of the last build's word_count / doc_flags arrays
+    const uint8_t* flags_dev = nullptr;
+
+    // ---- incremental updates.  The handle itself is the base segment; every sebm25_update adds one more
+    // (a handle of its own that only the base refers to).  A unit's live rows are in exactly one segment.
+    std::vector<sebm25_index*> deltas;
+    DevBuf dead_web, dead_news;  // bitmaps over this segment's unit spaces: rows of these units are dead here
+    bool has_dead = false;
+    uint64_t dead_rows = 0;
+    // sizes and sums over all segments (equal to V / n_docs / n_articles / P / P_web while there are no deltas)
+    uint32_t V_cur = 0, n_docs_cur = 0, n_articles_cur = 0;
+    DevBuf df_sum, term_rows_sum, chg_web, chg_news, upd_ids, upd_counts;
 
     std::vector<uint32_t> h_row_ptr, h_news_ptr;
     bool host_ptrs_valid = false;
@@ -74,6 +87,8 @@ struct sebm25_index {
 
     PhaseTimer timer;
 };
+
+extern "C" void sebm25_destroy(sebm25_index* ix);
 
 namespace {
 
@@ -317,13 +332,18 @@ int refresh_host_ptrs(sebm25_index* ix) {
     return SEBM25_OK;
 }
 
+void drop_deltas(sebm25_index* ix) {
+    for (sebm25_index* d : ix->deltas) sebm25_destroy(d);
+    ix->deltas.clear();
+}
+
 int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* tg) {
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "finalize: no index built on this handle");
-    const uint32_t* df_dev = ix->df_local.as<uint32_t>();
+    const uint32_t* df_dev = ix->deltas.empty() ? ix->df_local.as<uint32_t>() : ix->df_sum.as<uint32_t>();
     ix->has_df_global = false;
     if (df_global) {
-        HIP_TRY(ix, ix->df_global.ensure((size_t)ix->V * 4));
-        HIP_TRY(ix, hipMemcpyAsync(ix->df_global.p, df_global, (size_t)ix->V * 4, hipMemcpyDefault, ix->stream));
+        HIP_TRY(ix, ix->df_global.ensure((size_t)ix->V_cur * 4));
+        HIP_TRY(ix, hipMemcpyAsync(ix->df_global.p, df_global, (size_t)ix->V_cur * 4, hipMemcpyDefault, ix->stream));
         df_dev = ix->df_global.as<uint32_t>();
         ix->has_df_global = true;
     }
@@ -331,7 +351,7 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
     ix->N = ix->used_totals.n_done ? ix->used_totals.n_done : 1;  // `or 1`
     ix->avgdl = ix->used_totals.n_wc ? (double)ix->used_totals.sum_wc / (double)ix->used_totals.n_wc : 0.0;  // `or 0.0`
     phase_begin(ix, "idf");
-    launch_idf(df_dev, ix->V, ix->N, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
+    launch_idf(df_dev, ix->V_cur, ix->N, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
     phase_end(ix);
     HIP_TRY(ix, hipGetLastError());
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -339,30 +359,13 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
     return SEBM25_OK;
 }
 
-int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
-    if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
-    if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
-    if (in->n_rows > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
-    if (in->n_rows && (!in->term_id || !in->unit_id || !in->tf || !in->meta))
-        return fail(ix, SEBM25_E_INVALID, "build: a row array is NULL");
-    if (in->flags & ~SEBM25_ROWS_UNIT_MAJOR) return fail(ix, SEBM25_E_INVALID, "build: unknown flag");
-
-    ix->built = ix->finalized = false;
-    ix->host_ptrs_valid = false;
-    ix->h_row_ptr.resize((size_t)in->n_terms + 1);  // filled by the first search; sized here so that a search never allocates them
-    ix->h_news_ptr.resize(in->n_terms);
-    const uint64_t R = in->n_rows;
-    const uint32_t V = in->n_terms;
-    RowFmt fmt;
-    fmt.term_bits = bits_for(V);
-    fmt.unit_bits = bits_for(std::max<uint64_t>(std::max(in->n_docs, in->n_articles), 1));
-    fmt.tf_bits = 61 - fmt.term_bits - fmt.unit_bits;
-    if (fmt.tf_bits < 8)
-        return fail(ix, SEBM25_E_RANGE, "build: term and unit id spaces leave fewer than 8 bits for tf in the packed row");
-    ix->R = R; ix->V = V; ix->n_docs = in->n_docs; ix->n_articles = in->n_articles; ix->fmt = fmt;
-    phases_reset(ix);
-
-    // ---- device memory
+// Sorts the rows of a segment and writes its posting slots, list bounds, df and row counts.  The rows are the
+// caller's raw arrays (start_packed == nullptr) or packed rows that already sit in sort buffer A (compaction).
+// ix->R / V / fmt / n_docs / n_articles describe the segment; buffers are sized here.
+int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, bool unit_major, const uint8_t* flags_dev) {
+    const uint64_t R = ix->R;
+    const uint32_t V = ix->V;
+    const RowFmt fmt = ix->fmt;
     const size_t Rcap = std::max<uint64_t>(R, 1);
     // each sort buffer later holds the two posting slot arrays, padded by POST_PAD entries each
     HIP_TRY(ix, ix->sortA.ensure((Rcap + POST_PAD) * 8));
@@ -371,29 +374,8 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     HIP_TRY(ix, ix->news_ptr.ensure((size_t)V * 4));
     HIP_TRY(ix, ix->df_local.ensure((size_t)V * 4));
     HIP_TRY(ix, ix->term_rows.ensure((size_t)V * 4));
-    HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
-    HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
-    HIP_TRY(ix, ix->doc_len.ensure(std::max<size_t>(in->n_docs, 1) * 4));
-    HIP_TRY(ix, ix->scalars.ensure(64));
-    HIP_TRY(ix, hipMemsetAsync(ix->scalars.p, 0, 64, ix->stream));
-    HIP_TRY(ix, hipMemsetAsync(ix->doc_len.p, 0, std::max<size_t>(in->n_docs, 1) * 4, ix->stream));
     uint64_t* scal = ix->scalars.as<uint64_t>();
     uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
-
-    // ---- inputs
-    RawRows raw{};
-    const uint32_t* wc_dev = nullptr;
-    const uint8_t* flags_dev = nullptr;
-    int rc;
-    ix->h2d.clear();
-    if ((rc = stage_in(ix, in->term_id, R, ix->st_term, &raw.term))) return rc;
-    if ((rc = stage_in(ix, in->unit_id, R, ix->st_unit, &raw.unit))) return rc;
-    if ((rc = stage_in(ix, in->tf, R, ix->st_tf, &raw.tf))) return rc;
-    if ((rc = stage_in(ix, in->meta, R, ix->st_meta, &raw.meta))) return rc;
-    if ((rc = stage_in(ix, in->word_count, in->n_docs, ix->st_wc, &wc_dev))) return rc;
-    if ((rc = stage_in(ix, in->doc_flags, in->n_docs, ix->st_flags, &flags_dev))) return rc;
-    if ((rc = flush_h2d(ix))) return rc;
-
     uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
     uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
     const uint64_t* sorted_rows = nullptr;
@@ -408,7 +390,6 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         ix->n_pass = 0;
     } else {
         // ---- stable LSD radix sort on the key bits of the packed row
-        const bool unit_major = (in->flags & SEBM25_ROWS_UNIT_MAJOR) != 0;
         const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
         const int key_bits = 64 - key_lo;
         const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
@@ -424,10 +405,10 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
 
         BuildCtx ctx{};
         ctx.fmt = fmt;
-        ctx.n_terms = V; ctx.n_docs = in->n_docs; ctx.n_articles = in->n_articles;
+        ctx.n_terms = V; ctx.n_docs = ix->n_docs; ctx.n_articles = ix->n_articles;
         ctx.check_order = unit_major ? 1u : 0u;
         ctx.doc_len = ix->doc_len.as<uint32_t>();
-        ctx.doc_flags = in->n_docs ? flags_dev : nullptr;
+        ctx.doc_flags = ix->n_docs ? flags_dev : nullptr;
         ctx.err = err_dev;
 
         // at most ceil(54 key bits / 4-bit digits) = 14 passes
@@ -438,13 +419,14 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6", "sort_scatter_7",
                                            "sort_scatter_8", "sort_scatter_9", "sort_scatter_10", "sort_scatter_11", "sort_scatter_12", "sort_scatter_13", "sort_scatter_14", "sort_scatter_15"};
         if (n_pass > 16) return fail(ix, SEBM25_E_INTERNAL, "build: more than 16 sort passes");
-        const uint64_t* src_packed = nullptr;
+        const uint64_t* src_packed = start_packed;
         uint64_t* bufs[2] = {ix->sortA.as<uint64_t>(), ix->sortB.as<uint64_t>()};
+        const int first_dst = start_packed ? 1 : 0;  // packed rows start in buffer A: the first pass writes B
         int shift = key_lo;
         for (int p = 0; p < n_pass; ++p) {
             const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
-            const int mode = p == 0 ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
-            uint64_t* dst = bufs[p & 1];
+            const int mode = (p == 0 && !start_packed) ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
+            uint64_t* dst = bufs[(p + first_dst) & 1];
             unsigned short* prefix = ix->chunk_hist.as<unsigned short>();
             uint32_t* group_off = ix->group_off.as<uint32_t>();
             uint32_t* bin_start = ix->bin_start.as<uint32_t>();
@@ -463,7 +445,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         HIP_TRY(ix, hipGetLastError());
         const uint64_t* sorted = src_packed;
         sorted_rows = sorted;
-        uint64_t* other = bufs[n_pass & 1];  // the buffer the last pass did not write
+        uint64_t* other = sorted == bufs[0] ? bufs[1] : bufs[0];  // the buffer the last pass did not write
         // postings live in the free sort buffer: unit ids in its first half, weights in the second
         ix->post_unit = reinterpret_cast<uint32_t*>(other);
         ix->post_w = reinterpret_cast<uint32_t*>(other) + Rcap + POST_PAD;
@@ -485,18 +467,21 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
         launch_term_stats(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->stream);
         phase_end(ix);
     }
-    phase_begin(ix, "doc_stats");
-    launch_doc_stats(wc_dev, ix->doc_len.as<uint32_t>(), flags_dev, in->n_docs, scal + 2, ix->stream);
-    phase_end(ix);
+    ix->sorted_rows = sorted_rows;
     HIP_TRY(ix, hipGetLastError());
+    return SEBM25_OK;
+}
 
-    uint64_t h[8];
+// reads the counters a build leaves in ix->scalars, runs the rare exact second look, reports device-side errors
+int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
     HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
     if ((dev_err & DEV_NEED_FIXUP) && !(dev_err & (DEV_ERR_RANGE | DEV_ERR_ORDER))) {
         // rare runs the streaming kernel leaves to an exact second look
-        launch_postings_fixup(sorted_rows, R, fmt, ix->post_w, err_dev, ix->stream);
+        launch_postings_fixup(ix->sorted_rows, ix->R, ix->fmt, ix->post_w, err_dev, ix->stream);
         HIP_TRY(ix, hipGetLastError());
         HIP_TRY(ix, hipMemcpyAsync(h + 7, scal + 7, 8, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -511,11 +496,307 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     ix->P = h[0];
     ix->WH = h[1];
     ix->P_web = h[5];
+    return SEBM25_OK;
+}
+
+int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
+    if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
+    if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
+    if (in->n_rows > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
+    if (in->n_rows && (!in->term_id || !in->unit_id || !in->tf || !in->meta))
+        return fail(ix, SEBM25_E_INVALID, "build: a row array is NULL");
+    if (in->flags & ~SEBM25_ROWS_UNIT_MAJOR) return fail(ix, SEBM25_E_INVALID, "build: unknown flag");
+
+    ix->built = ix->finalized = false;
+    ix->host_ptrs_valid = false;
+    drop_deltas(ix);
+    ix->has_dead = false;
+    ix->dead_rows = 0;
+    ix->sorted_rows = nullptr;
+    ix->h_row_ptr.resize((size_t)in->n_terms + 1);  // filled by the first search; sized here so that a search never allocates them
+    ix->h_news_ptr.resize(in->n_terms);
+    const uint64_t R = in->n_rows;
+    const uint32_t V = in->n_terms;
+    RowFmt fmt;
+    fmt.term_bits = bits_for(V);
+    fmt.unit_bits = bits_for(std::max<uint64_t>(std::max(in->n_docs, in->n_articles), 1));
+    fmt.tf_bits = 61 - fmt.term_bits - fmt.unit_bits;
+    if (fmt.tf_bits < 8)
+        return fail(ix, SEBM25_E_RANGE, "build: term and unit id spaces leave fewer than 8 bits for tf in the packed row");
+    ix->R = R; ix->V = V; ix->n_docs = in->n_docs; ix->n_articles = in->n_articles; ix->fmt = fmt;
+    ix->V_cur = V; ix->n_docs_cur = in->n_docs; ix->n_articles_cur = in->n_articles;
+    phases_reset(ix);
+
+    // ---- device memory
+    HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
+    HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
+    HIP_TRY(ix, ix->doc_len.ensure(std::max<size_t>(in->n_docs, 1) * 4));
+    HIP_TRY(ix, ix->scalars.ensure(64));
+    HIP_TRY(ix, hipMemsetAsync(ix->scalars.p, 0, 64, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(ix->doc_len.p, 0, std::max<size_t>(in->n_docs, 1) * 4, ix->stream));
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    const size_t Rcap = std::max<uint64_t>(R, 1);
+    HIP_TRY(ix, ix->sortA.ensure((Rcap + POST_PAD) * 8));  // before the inputs are staged: a failure here costs no copy
+    HIP_TRY(ix, ix->sortB.ensure((Rcap + POST_PAD) * 8));
+
+    // ---- inputs
+    RawRows raw{};
+    const uint32_t* wc_dev = nullptr;
+    const uint8_t* flags_dev = nullptr;
+    int rc;
+    ix->h2d.clear();
+    if ((rc = stage_in(ix, in->term_id, R, ix->st_term, &raw.term))) return rc;
+    if ((rc = stage_in(ix, in->unit_id, R, ix->st_unit, &raw.unit))) return rc;
+    if ((rc = stage_in(ix, in->tf, R, ix->st_tf, &raw.tf))) return rc;
+    if ((rc = stage_in(ix, in->meta, R, ix->st_meta, &raw.meta))) return rc;
+    if ((rc = stage_in(ix, in->word_count, in->n_docs, ix->st_wc, &wc_dev))) return rc;
+    if ((rc = stage_in(ix, in->doc_flags, in->n_docs, ix->st_flags, &flags_dev))) return rc;
+    if ((rc = flush_h2d(ix))) return rc;
+    ix->wc_dev = wc_dev;
+    ix->flags_dev = flags_dev;
+
+    if ((rc = sort_and_post(ix, raw, nullptr, (in->flags & SEBM25_ROWS_UNIT_MAJOR) != 0, flags_dev))) return rc;
+    phase_begin(ix, "doc_stats");
+    launch_doc_stats(wc_dev, ix->doc_len.as<uint32_t>(), flags_dev, in->n_docs, scal + 2, ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+
+    uint64_t h[8];
+    if ((rc = collect_build(ix, h))) return rc;
     ix->local_totals.n_done = h[2];
     ix->local_totals.n_wc = h[3];
     ix->local_totals.sum_wc = h[4];
     ix->local_totals.n_postings = h[0];
     ix->built = true;
+    return SEBM25_OK;
+}
+
+// ---- compaction: all segments folded into one, on the device --------------------------------
+int do_compact(sebm25_index* ix);
+
+// ---- incremental update --------------------------------------------------------------------
+std::vector<sebm25_index*> all_segments(sebm25_index* ix) {
+    std::vector<sebm25_index*> v{ix};
+    v.insert(v.end(), ix->deltas.begin(), ix->deltas.end());
+    return v;
+}
+
+int ensure_dead_bitmaps(sebm25_index* ix, sebm25_index* seg) {
+    if (seg->has_dead) return SEBM25_OK;
+    const size_t ww = ((size_t)seg->n_docs + 31) / 32 + 1, wn = ((size_t)seg->n_articles + 31) / 32 + 1;
+    HIP_TRY(ix, seg->dead_web.ensure(ww * 4));
+    HIP_TRY(ix, seg->dead_news.ensure(wn * 4));
+    HIP_TRY(ix, hipMemsetAsync(seg->dead_web.p, 0, ww * 4, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(seg->dead_news.p, 0, wn * 4, ix->stream));
+    seg->has_dead = true;
+    return SEBM25_OK;
+}
+
+// df and row counts per term summed over the segments
+int sum_term_counts(sebm25_index* ix) {
+    const size_t V = ix->V_cur;
+    HIP_TRY(ix, ix->df_sum.ensure(V * 4));
+    HIP_TRY(ix, ix->term_rows_sum.ensure(V * 4));
+    HIP_TRY(ix, hipMemsetAsync(ix->df_sum.p, 0, V * 4, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(ix->term_rows_sum.p, 0, V * 4, ix->stream));
+    for (sebm25_index* seg : all_segments(ix)) {
+        launch_add_u32(ix->df_sum.as<uint32_t>(), seg->df_local.as<uint32_t>(), seg->V, ix->stream);
+        launch_add_u32(ix->term_rows_sum.as<uint32_t>(), seg->term_rows.as<uint32_t>(), seg->V, ix->stream);
+    }
+    HIP_TRY(ix, hipGetLastError());
+    return SEBM25_OK;
+}
+
+// grows a per-term or per-doc array, keeping what it holds and zero-filling the rest
+int grow_keep(sebm25_index* ix, DevBuf& buf, size_t old_bytes, size_t new_bytes) {
+    if (new_bytes <= buf.cap) {
+        if (new_bytes > old_bytes) HIP_TRY(ix, hipMemsetAsync(static_cast<char*>(buf.p) + old_bytes, 0, new_bytes - old_bytes, ix->stream));
+        return SEBM25_OK;
+    }
+    DevBuf nb;
+    HIP_TRY(ix, nb.ensure(new_bytes));
+    hipError_t e = hipSuccess;
+    if (old_bytes) e = hipMemcpyAsync(nb.p, buf.p, old_bytes, hipMemcpyDeviceToDevice, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(static_cast<char*>(nb.p) + old_bytes, 0, new_bytes - old_bytes, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        nb.release();
+        HIP_TRY(ix, e);
+    }
+    buf.release();
+    buf = nb;
+    return SEBM25_OK;
+}
+
+int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs, uint32_t n_cd, const uint32_t* chg_arts,
+              uint32_t n_ca) {
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "update: no index built on this handle");
+    if (!in) return fail(ix, SEBM25_E_INVALID, "update: rows is NULL");
+    if ((n_cd && !chg_docs) || (n_ca && !chg_arts)) return fail(ix, SEBM25_E_INVALID, "update: a list of changed units is NULL");
+    if (in->n_terms < ix->V_cur || in->n_docs < ix->n_docs_cur || in->n_articles < ix->n_articles_cur)
+        return fail(ix, SEBM25_E_INVALID, "update: the term, doc and article id spaces can only grow");
+    if (ix->deltas.size() >= 64) return fail(ix, SEBM25_E_STATE, "update: 64 update segments are held; call sebm25_compact");
+    const uint32_t n_docs = in->n_docs, n_arts = in->n_articles, V = in->n_terms;
+    int rc;
+
+    // ---- the units this update replaces or removes, as bitmaps over the new id spaces
+    const size_t ww = ((size_t)n_docs + 31) / 32 + 1, wn = ((size_t)n_arts + 31) / 32 + 1;
+    HIP_TRY(ix, ix->chg_web.ensure(ww * 4));
+    HIP_TRY(ix, ix->chg_news.ensure(wn * 4));
+    HIP_TRY(ix, hipMemsetAsync(ix->chg_web.p, 0, ww * 4, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(ix->chg_news.p, 0, wn * 4, ix->stream));
+    HIP_TRY(ix, ix->upd_ids.ensure(((size_t)n_cd + n_ca + 1) * 4));
+    uint32_t* ids_dev = ix->upd_ids.as<uint32_t>();
+    if (n_cd) HIP_TRY(ix, hipMemcpyAsync(ids_dev, chg_docs, (size_t)n_cd * 4, hipMemcpyDefault, ix->stream));
+    if (n_ca) HIP_TRY(ix, hipMemcpyAsync(ids_dev + n_cd, chg_arts, (size_t)n_ca * 4, hipMemcpyDefault, ix->stream));
+    launch_bitmap_set(ids_dev, n_cd, n_docs, ix->chg_web.as<uint32_t>(), ix->stream);
+    launch_bitmap_set(ids_dev + n_cd, n_ca, n_arts, ix->chg_news.as<uint32_t>(), ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));  // the id lists may be pageable host memory
+
+    // ---- the new rows become a segment of their own (nothing that exists is touched until this has succeeded)
+    sebm25_index* seg = new (std::nothrow) sebm25_index();
+    if (!seg) return fail(ix, SEBM25_E_NOMEM, "update: out of host memory");
+    seg->device = ix->device;
+    seg->stream = ix->stream;
+    seg->sort_bits = ix->sort_bits;
+    rc = do_build_local(seg, in);
+    uint32_t listed_err = 0;
+    if (!rc && seg->R) {
+        uint32_t* err_dev = reinterpret_cast<uint32_t*>(seg->scalars.as<uint64_t>() + 7);
+        hipError_t e = hipMemsetAsync(err_dev, 0, 4, ix->stream);
+        launch_check_listed(seg->sorted_rows, seg->R, seg->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(), err_dev,
+                            ix->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&listed_err, err_dev, 4, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(seg, SEBM25_E_HIP, std::string("update: ") + hipGetErrorString(e));
+        } else if (listed_err) {
+            rc = fail(seg, SEBM25_E_INVALID, "update: a row belongs to a unit that is not listed as changed");
+        }
+    }
+    if (rc) {
+        const std::string msg = seg->err;
+        sebm25_destroy(seg);
+        return fail(ix, rc, msg);
+    }
+
+    // ---- in every segment that exists, the rows of the changed units die
+    const std::vector<sebm25_index*> segs = all_segments(ix);
+    HIP_TRY(ix, ix->upd_counts.ensure(segs.size() * 4 * 8));
+    HIP_TRY(ix, hipMemsetAsync(ix->upd_counts.p, 0, segs.size() * 4 * 8, ix->stream));
+    for (size_t s = 0; s < segs.size(); ++s) {
+        sebm25_index* g = segs[s];
+        if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
+        launch_tombstone(g->sorted_rows, g->R, g->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(),
+                         g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
+                         g->term_rows.as<uint32_t>(), ix->upd_counts.as<unsigned long long>() + 4 * s, ix->stream);
+        launch_bitmap_or(g->dead_web.as<uint32_t>(), ix->chg_web.as<uint32_t>(), (uint32_t)(((size_t)g->n_docs + 31) / 32), ix->stream);
+        launch_bitmap_or(g->dead_news.as<uint32_t>(), ix->chg_news.as<uint32_t>(), (uint32_t)(((size_t)g->n_articles + 31) / 32), ix->stream);
+    }
+    HIP_TRY(ix, hipGetLastError());
+    std::vector<unsigned long long> counts(segs.size() * 4);
+    HIP_TRY(ix, hipMemcpyAsync(counts.data(), ix->upd_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+
+    // ---- per-doc body lengths: the new segment's for changed docs
+    if ((rc = grow_keep(ix, ix->doc_len, (size_t)ix->n_docs_cur * 4, std::max<size_t>(n_docs, 1) * 4))) return rc;
+    launch_doc_len_merge(ix->doc_len.as<uint32_t>(), seg->doc_len.as<uint32_t>(), ix->chg_web.as<uint32_t>(), n_docs, ix->stream);
+
+    // ---- the handle now spans the new id spaces
+    if (n_docs > ix->n_docs_cur) ix->has_rank_web = false;      // the rank arrays no longer cover every unit: the caller sets them again
+    if (n_arts > ix->n_articles_cur) ix->has_rank_news = false;
+    ix->deltas.push_back(seg);
+    ix->V_cur = V; ix->n_docs_cur = n_docs; ix->n_articles_cur = n_arts;
+    HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
+    HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
+    if ((rc = sum_term_counts(ix))) return rc;
+
+    // ---- document totals from the documents columns as they are now (bm25_stats.py:9,12)
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    HIP_TRY(ix, hipMemsetAsync(scal + 2, 0, 24, ix->stream));
+    launch_doc_stats(seg->wc_dev, ix->doc_len.as<uint32_t>(), seg->flags_dev, n_docs, scal + 2, ix->stream);
+    HIP_TRY(ix, hipGetLastError());
+    uint64_t h[3];
+    HIP_TRY(ix, hipMemcpyAsync(h, scal + 2, 24, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    uint64_t P_all = seg->P;
+    for (size_t s = 0; s < segs.size(); ++s) {
+        sebm25_index* g = segs[s];
+        g->P -= counts[4 * s];
+        g->P_web -= counts[4 * s + 1];
+        g->WH -= counts[4 * s + 2];
+        g->dead_rows += counts[4 * s + 3];
+        P_all += g->P;
+    }
+    ix->local_totals.n_done = h[0];
+    ix->local_totals.n_wc = h[1];
+    ix->local_totals.sum_wc = h[2];
+    ix->local_totals.n_postings = P_all;
+    ix->finalized = false;
+    return SEBM25_OK;
+}
+
+
+int do_compact(sebm25_index* ix) {
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "compact: no index built on this handle");
+    if (ix->deltas.empty() && ix->dead_rows == 0) return SEBM25_OK;
+    const std::vector<sebm25_index*> segs = all_segments(ix);
+    uint64_t total = 0;
+    for (const sebm25_index* g : segs) total += g->R - g->dead_rows;
+    if (total > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "compact: more than 2^32 - 4096 live rows");
+    RowFmt fmt;
+    fmt.term_bits = bits_for(ix->V_cur);
+    fmt.unit_bits = bits_for(std::max<uint64_t>(std::max(ix->n_docs_cur, ix->n_articles_cur), 1));
+    fmt.tf_bits = 61 - fmt.term_bits - fmt.unit_bits;
+    for (const sebm25_index* g : segs)
+        if (fmt.tf_bits < g->fmt.tf_bits && fmt.tf_bits < 32)
+            return fail(ix, SEBM25_E_RANGE, "compact: the grown id spaces leave too few bits for tf in the packed row (rebuild)");
+    int rc;
+    for (sebm25_index* g : segs)
+        if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
+    // ---- the live rows of every segment, in the common row format, into a new sort buffer
+    const size_t cap = std::max<uint64_t>(total, 1);
+    DevBuf nA;
+    HIP_TRY(ix, nA.ensure((cap + POST_PAD) * 8));
+    HIP_TRY(ix, ix->upd_counts.ensure(64));
+    hipError_t e = hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream);
+    for (sebm25_index* g : segs)
+        launch_gather_live(g->sorted_rows, g->R, g->fmt, fmt, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(),
+                           nA.as<uint64_t>(), ix->upd_counts.as<unsigned long long>(), ix->stream);
+    unsigned long long n_live = 0;
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_live, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess || n_live != total) {
+        nA.release();
+        if (e != hipSuccess) HIP_TRY(ix, e);
+        return fail(ix, SEBM25_E_INTERNAL, "compact: live row count disagrees with the segments' bookkeeping");
+    }
+    // ---- from here on the handle is the one new segment
+    drop_deltas(ix);
+    ix->sortA.release();
+    ix->sortA = nA;
+    ix->R = n_live; ix->V = ix->V_cur; ix->n_docs = ix->n_docs_cur; ix->n_articles = ix->n_articles_cur; ix->fmt = fmt;
+    ix->has_dead = false;
+    ix->dead_rows = 0;
+    ix->host_ptrs_valid = false;
+    ix->h_row_ptr.resize((size_t)ix->V + 1);
+    ix->h_news_ptr.resize(ix->V);
+    phases_reset(ix);
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    HIP_TRY(ix, hipMemsetAsync(scal, 0, 64, ix->stream));
+    // sort_and_post sizes buffer B; buffer A already holds the rows (ensure keeps a buffer that is large enough)
+    if ((rc = sort_and_post(ix, RawRows{}, ix->sortA.as<uint64_t>(), false, nullptr))) {
+        ix->built = false;
+        return rc;
+    }
+    uint64_t h[8];
+    if ((rc = collect_build(ix, h))) {
+        ix->built = false;
+        return rc;
+    }
+    ix->local_totals.n_postings = ix->P;
     return SEBM25_OK;
 }
 
@@ -564,9 +845,14 @@ int sebm25_create(int device, sebm25_index** out) {
 
 void sebm25_destroy(sebm25_index* ix) {
     if (!ix) return;
+    for (sebm25_index* d : ix->deltas) sebm25_destroy(d);
+    ix->deltas.clear();
     {
         DeviceGuard g(ix->device);
         (void)hipStreamSynchronize(ix->stream);
+        for (DevBuf* b : {&ix->dead_web, &ix->dead_news, &ix->df_sum, &ix->term_rows_sum, &ix->chg_web, &ix->chg_news, &ix->upd_ids,
+                          &ix->upd_counts})
+            b->release();
         DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->group_off, &ix->bin_start, &ix->scan_tmp, &ix->row_ptr, &ix->news_ptr,
                          &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
                          &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
@@ -641,13 +927,44 @@ int sebm25_build(sebm25_index* ix, const sebm25_rows* rows) {
     ABI_CATCH(ix)
 }
 
+int sebm25_update_local(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* changed_docs, uint32_t n_changed_docs,
+                        const uint32_t* changed_articles, uint32_t n_changed_articles) {
+    ABI_TRY
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "update_local: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    return do_update(ix, rows, changed_docs, n_changed_docs, changed_articles, n_changed_articles);
+    ABI_CATCH(ix)
+}
+
+int sebm25_update(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* changed_docs, uint32_t n_changed_docs,
+                  const uint32_t* changed_articles, uint32_t n_changed_articles) {
+    ABI_TRY
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "update: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    int rc = do_update(ix, rows, changed_docs, n_changed_docs, changed_articles, n_changed_articles);
+    if (rc) return rc;
+    return do_finalize(ix, nullptr, nullptr);
+    ABI_CATCH(ix)
+}
+
+int sebm25_compact(sebm25_index* ix) {
+    ABI_TRY
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "compact: handle is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    return do_compact(ix);
+    ABI_CATCH(ix)
+}
+
 int sebm25_local_stats(sebm25_index* ix, uint32_t* df_out, sebm25_doc_totals* totals_out) {
     ABI_TRY
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "local_stats: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "local_stats: no index built on this handle");
-    int rc = copy_out(ix, df_out, ix->df_local.p, (size_t)ix->V * 4);
+    int rc = copy_out(ix, df_out, ix->deltas.empty() ? ix->df_local.p : ix->df_sum.p, (size_t)ix->V_cur * 4);
     if (rc) return rc;
     if (totals_out) *totals_out = ix->local_totals;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -663,9 +980,10 @@ int sebm25_get_stats(sebm25_index* ix, uint32_t* df_out, double* idf_out, uint32
     DeviceGuard g(ix->device);
     if (!ix->finalized) return fail(ix, SEBM25_E_STATE, "get_stats: statistics are not finalized");
     int rc;
-    if ((rc = copy_out(ix, df_out, ix->has_df_global ? ix->df_global.p : ix->df_local.p, (size_t)ix->V * 4))) return rc;
-    if ((rc = copy_out(ix, idf_out, ix->idf.p, (size_t)ix->V * 8))) return rc;
-    if ((rc = copy_out(ix, term_rows_out, ix->term_rows.p, (size_t)ix->V * 4))) return rc;
+    const void* df_src = ix->has_df_global ? ix->df_global.p : (ix->deltas.empty() ? ix->df_local.p : ix->df_sum.p);
+    if ((rc = copy_out(ix, df_out, df_src, (size_t)ix->V_cur * 4))) return rc;
+    if ((rc = copy_out(ix, idf_out, ix->idf.p, (size_t)ix->V_cur * 8))) return rc;
+    if ((rc = copy_out(ix, term_rows_out, ix->deltas.empty() ? ix->term_rows.p : ix->term_rows_sum.p, (size_t)ix->V_cur * 4))) return rc;
     if (n_docs_out) *n_docs_out = ix->N;
     if (avgdl_out) *avgdl_out = ix->avgdl;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -679,7 +997,7 @@ int sebm25_get_doc_len(sebm25_index* ix, uint32_t* doc_len_out) {
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_doc_len: no index built on this handle");
-    int rc = copy_out(ix, doc_len_out, ix->doc_len.p, (size_t)ix->n_docs * 4);
+    int rc = copy_out(ix, doc_len_out, ix->doc_len.p, (size_t)ix->n_docs_cur * 4);
     if (rc) return rc;
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     return SEBM25_OK;
@@ -696,10 +1014,10 @@ int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present) 
     const uint8_t* pr_dev = nullptr;
     int rc;
     ix->h2d.clear();
-    if ((rc = stage_in(ix, idf, ix->V, ix->st_misc, &idf_dev))) return rc;
-    if ((rc = stage_in(ix, present, ix->V, ix->st_flags, &pr_dev))) return rc;
+    if ((rc = stage_in(ix, idf, ix->V_cur, ix->st_misc, &idf_dev))) return rc;
+    if ((rc = stage_in(ix, present, ix->V_cur, ix->st_tf, &pr_dev))) return rc;
     if ((rc = flush_h2d(ix))) return rc;
-    launch_idf_override(idf_dev, pr_dev, ix->V, ix->idf_used.as<double>(), ix->stream);
+    launch_idf_override(idf_dev, pr_dev, ix->V_cur, ix->idf_used.as<double>(), ix->stream);
     HIP_TRY(ix, hipGetLastError());
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     ix->finalized = true;
@@ -722,7 +1040,7 @@ int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank) {
         return SEBM25_OK;
     }
     DevBuf& buf = web ? ix->url_rank_web : ix->url_rank_news;
-    const size_t n = web ? ix->n_docs : ix->n_articles;
+    const size_t n = web ? ix->n_docs_cur : ix->n_articles_cur;
     HIP_TRY(ix, buf.ensure(std::max<size_t>(n, 1) * 4));
     HIP_TRY(ix, hipMemcpyAsync(buf.p, rank, n * 4, hipMemcpyDefault, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -745,12 +1063,20 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_info: no index built on this handle");
-    out->n_rows = ix->R;
+    out->n_rows = ix->R - ix->dead_rows;
     out->n_postings = ix->P;
     out->n_web_postings = ix->P_web;
-    out->n_terms = ix->V;
-    out->n_docs = ix->n_docs;
-    out->n_articles = ix->n_articles;
+    out->n_dead_rows = ix->dead_rows;
+    for (const sebm25_index* d : ix->deltas) {
+        out->n_rows += d->R - d->dead_rows;
+        out->n_postings += d->P;
+        out->n_web_postings += d->P_web;
+        out->n_dead_rows += d->dead_rows;
+    }
+    out->n_segments = 1u + (uint32_t)ix->deltas.size();
+    out->n_terms = ix->V_cur;
+    out->n_docs = ix->n_docs_cur;
+    out->n_articles = ix->n_articles_cur;
     out->term_bits = (uint32_t)ix->fmt.term_bits;
     out->unit_bits = (uint32_t)ix->fmt.unit_bits;
     out->tf_bits = (uint32_t)ix->fmt.tf_bits;
@@ -766,42 +1092,66 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
     if (!ix->built) return fail(ix, SEBM25_E_STATE, "get_postings: no index built on this handle");
-    int rc = refresh_host_ptrs(ix);
-    if (rc) return rc;
     if ((row_ptr && is_device_ptr(row_ptr)) || (news_ptr && is_device_ptr(news_ptr)))
         return fail(ix, SEBM25_E_INVALID, "get_postings: row_ptr and news_ptr must be host arrays");
-    // The index keeps one slot per sorted row (holes where rows were merged or filtered); this
-    // export compacts it on the host into the CSR the ABI describes.
-    const size_t R = ix->R;
-    std::vector<uint32_t> su(R), sw(R);
-    if (R) {
-        HIP_TRY(ix, hipMemcpyAsync(su.data(), ix->post_unit, R * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(ix, hipMemcpyAsync(sw.data(), ix->post_w, R * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    // Every segment keeps one slot per sorted row (holes where rows were merged, filtered or have died); this
+    // export compacts them on the host into the CSR the ABI describes, a term's postings from several segments
+    // merged by unit.
+    const std::vector<sebm25_index*> segs = all_segments(ix);
+    std::vector<std::vector<uint32_t>> su(segs.size()), sw(segs.size());
+    uint64_t P_all = 0;
+    for (size_t s = 0; s < segs.size(); ++s) {
+        sebm25_index* seg = segs[s];
+        seg->stream = ix->stream;
+        int rc = refresh_host_ptrs(seg);
+        if (rc) {
+            if (seg != ix) ix->err = seg->err;
+            return rc;
+        }
+        su[s].resize(seg->R);
+        sw[s].resize(seg->R);
+        if (seg->R) {
+            HIP_TRY(ix, hipMemcpyAsync(su[s].data(), seg->post_unit, (size_t)seg->R * 4, hipMemcpyDeviceToHost, ix->stream));
+            HIP_TRY(ix, hipMemcpyAsync(sw[s].data(), seg->post_w, (size_t)seg->R * 4, hipMemcpyDeviceToHost, ix->stream));
+        }
+        P_all += seg->P;
     }
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     const bool want_posts = post_unit || post_weight;
     std::vector<uint32_t> cu, cw;
     if (want_posts) {
-        cu.reserve(ix->P);
-        cw.reserve(ix->P);
+        cu.reserve(P_all);
+        cw.reserve(P_all);
     }
+    std::vector<std::pair<uint32_t, uint32_t>> run;
     uint64_t n = 0;
-    for (size_t t = 0; t < ix->V; ++t) {
+    for (size_t t = 0; t < ix->V_cur; ++t) {
         if (row_ptr) row_ptr[t] = n;
-        const uint32_t b = ix->h_row_ptr[t], m = ix->h_news_ptr[t], e = ix->h_row_ptr[t + 1];
-        for (uint32_t i = b; i < e; ++i) {
-            if (i == m && news_ptr) news_ptr[t] = n;
-            if (sw[i] == POST_HOLE) continue;
-            if (want_posts) {
-                cu.push_back(su[i]);
-                cw.push_back(sw[i]);
+        for (int news = 0; news < 2; ++news) {
+            if (news && news_ptr) news_ptr[t] = n;
+            run.clear();
+            size_t from = 0;
+            for (size_t s = 0; s < segs.size(); ++s) {
+                const sebm25_index* seg = segs[s];
+                if (t >= seg->V) continue;
+                const uint32_t b = news ? seg->h_news_ptr[t] : seg->h_row_ptr[t];
+                const uint32_t e = news ? seg->h_row_ptr[t + 1] : seg->h_news_ptr[t];
+                const size_t before = run.size();
+                for (uint32_t i = b; i < e; ++i)
+                    if (sw[s][i] != POST_HOLE) run.emplace_back(su[s][i], sw[s][i]);
+                if (run.size() > before) ++from;
             }
-            ++n;
+            if (from > 1) std::sort(run.begin(), run.end());
+            n += run.size();
+            if (want_posts)
+                for (const auto& pr : run) {
+                    cu.push_back(pr.first);
+                    cw.push_back(pr.second);
+                }
         }
-        if (m == e && news_ptr) news_ptr[t] = n;
     }
-    if (row_ptr) row_ptr[ix->V] = n;
-    if (n != ix->P) return fail(ix, SEBM25_E_INTERNAL, "get_postings: slot array and posting count disagree");
+    if (row_ptr) row_ptr[ix->V_cur] = n;
+    if (n != P_all) return fail(ix, SEBM25_E_INTERNAL, "get_postings: slot arrays and posting counts disagree");
     if (post_unit && n) HIP_TRY(ix, hipMemcpy(post_unit, cu.data(), n * 4, hipMemcpyDefault));
     if (post_weight && n) HIP_TRY(ix, hipMemcpy(post_weight, cw.data(), n * 4, hipMemcpyDefault));
     return SEBM25_OK;
@@ -910,7 +1260,9 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
     return SEBM25_OK;
 }
 
-int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, PlanInfo& info) {
+// tmp_base: when given, every item writes a temporary list, query q's lists of this plan being tmp_base[q], tmp_base[q] + 1, ...
+// (several index segments scored for one batch); first / nlists are then the caller's business
+int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, PlanInfo& info, const uint32_t* tmp_base = nullptr) {
     if (info.n_items > st.item_cap) return fail(ix, SEBM25_E_RANGE, "search: too many work items for the plan storage");
     const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
     const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
@@ -918,8 +1270,10 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
     uint32_t n = 0, n_tmp = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
         const uint32_t ns = st.q_ns[q];
-        st.first[q] = ns > 1 ? n_tmp : 0u;
-        st.nlists[q] = ns > 1 ? ns : 0u;
+        if (!tmp_base) {
+            st.first[q] = ns > 1 ? n_tmp : 0u;
+            st.nlists[q] = ns > 1 ? ns : 0u;
+        }
         for (uint32_t sl = 0; sl < ns; ++sl) {
             QItem it{};
             it.q = q;
@@ -928,8 +1282,8 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
             it.order = st.q_nt[q] >> 8;
             it.unit_lo = (uint32_t)((uint64_t)n_units * sl / ns);
             it.unit_hi = sl + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (sl + 1) / ns);
-            it.direct = ns == 1;
-            it.out_slot = ns == 1 ? q : n_tmp++;
+            it.direct = !tmp_base && ns == 1;
+            it.out_slot = tmp_base ? tmp_base[q] + sl : (ns == 1 ? q : n_tmp++);
             st.unsorted[n] = it;
             st.item_len[n] = st.q_len[q] / ns;
             ++n;
@@ -967,6 +1321,38 @@ struct SearchBufs {  // device memory of one search call
     uint32_t *t_unit, *t_mat, *t_tie, *t_count;
     double* t_score;
 };
+
+// uploads one segment's plan and launches its scoring kernels; statistics, url ranks and unit bases are the
+// handle's (ix), lists and slots the segment's (seg; the handle itself is the base segment)
+int score_segment(sebm25_index* ix, const sebm25_index* seg, bool news, uint32_t k, const PlanStore& st, const PlanInfo& info,
+                  const SearchBufs& b, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie, uint32_t* d_count) {
+    phase_begin(ix, "search_plan_h2d");
+    HIP_TRY(ix, hipMemcpyAsync(b.items, st.items, (size_t)info.n_items * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
+    if (info.n_flat)
+        HIP_TRY(ix, hipMemcpyAsync(b.terms, st.flat, (size_t)info.n_flat * 4, hipMemcpyHostToDevice, ix->stream));
+    phase_end(ix);
+    ScoreArgs a{};
+    a.row_ptr = seg->row_ptr.as<uint32_t>();
+    a.news_ptr = seg->news_ptr.as<uint32_t>();
+    a.post_unit = seg->post_unit;
+    a.post_w = seg->post_w;
+    a.idf_used = ix->idf_used.as<double>();
+    a.url_rank = news ? (ix->has_rank_news ? ix->url_rank_news.as<uint32_t>() : nullptr)
+                      : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);
+    a.unit_base = news ? ix->news_base : ix->web_base;
+    a.news = news ? 1 : 0;
+    a.items = b.items;
+    a.q_terms = b.terms;
+    a.n_items = info.n_items;
+    a.k = k;
+    a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
+    a.tmp_unit = b.t_unit; a.tmp_score = b.t_score; a.tmp_matched = b.t_mat; a.tmp_tie = b.t_tie; a.tmp_count = b.t_count;
+    phase_begin(ix, "score_topk");
+    launch_score(a, info.n_by_t, ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+    return SEBM25_OK;
+}
 
 // launches scoring (+ the merge of split queries) for a finished plan; results land in d_*
 int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, const PlanStore& st, const PlanInfo& info,
@@ -1015,6 +1401,93 @@ int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, cons
     return SEBM25_OK;
 }
 
+// plan storage of sebm25_search in a segment's own vectors (grown on demand); items are sized by the caller
+void plan_store_of(sebm25_index* seg, const uint64_t* q_offsets, uint32_t n_queries, PlanStore& st) {
+    SearchPlanVecs& v = seg->plan_vecs;
+    v.flat.resize(std::max<size_t>(q_offsets[n_queries], 1));
+    for (std::vector<uint32_t>* x : {&v.q_toff, &v.q_nt, &v.q_ns, &v.first, &v.nlists}) x->resize(n_queries);
+    v.q_len.resize(n_queries);
+    v.bucket.resize(plan_buckets() + 1);
+    st.flat = v.flat.data(); st.flat_cap = v.flat.size();
+    st.q_toff = v.q_toff.data(); st.q_nt = v.q_nt.data(); st.q_ns = v.q_ns.data(); st.q_len = v.q_len.data();
+    st.first = v.first.data(); st.nlists = v.nlists.data(); st.bucket = v.bucket.data();
+}
+void plan_items_of(sebm25_index* seg, uint32_t n_items, PlanStore& st) {
+    SearchPlanVecs& v = seg->plan_vecs;
+    v.items.resize(n_items); v.unsorted.resize(n_items); v.item_len.resize(n_items);
+    st.items = v.items.data(); st.unsorted = v.unsorted.data(); st.item_len = v.item_len.data(); st.item_cap = n_items;
+}
+
+// A batch over an index that has update segments: every segment is scored on its own (each unit's live rows sit
+// in exactly one segment, so a segment's scores are complete), every work item writes a temporary list, and one
+// merge per query cuts the lists of all segments to the best k.
+int search_segments(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
+                    uint32_t k, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie, uint32_t* d_count) {
+    std::vector<sebm25_index*> segs{ix};
+    segs.insert(segs.end(), ix->deltas.begin(), ix->deltas.end());
+    const size_t S = segs.size();
+    std::vector<PlanStore> st(S);
+    std::vector<PlanInfo> info(S);
+    std::vector<std::vector<uint32_t>> tmp_base(S, std::vector<uint32_t>(n_queries));
+    std::vector<uint32_t> first(n_queries), nlists(n_queries);
+    int rc;
+    for (size_t s = 0; s < S; ++s) {
+        sebm25_index* seg = segs[s];
+        seg->stream = ix->stream;
+        if ((rc = refresh_host_ptrs(seg)) || (plan_store_of(seg, q_offsets, n_queries, st[s]), false) ||
+            (rc = plan_pass1(seg, news, q_terms, q_offsets, n_queries, k, st[s], info[s], ~0ull))) {
+            if (seg != ix) ix->err = seg->err;
+            return rc;
+        }
+    }
+    uint32_t n_tmp = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        first[q] = n_tmp;
+        for (size_t s = 0; s < S; ++s) {
+            tmp_base[s][q] = n_tmp;
+            n_tmp += st[s].q_ns[q];
+        }
+        nlists[q] = n_tmp - first[q];
+    }
+    const size_t tk = (size_t)std::max(n_tmp, 1u) * k;
+    HIP_TRY(ix, ix->t_unit.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_score.ensure(tk * 8));
+    HIP_TRY(ix, ix->t_mat.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_tie.ensure(tk * 4));
+    HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(n_tmp, 1u) * 4));
+    HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
+    HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
+    for (size_t s = 0; s < S; ++s) {
+        sebm25_index* seg = segs[s];
+        plan_items_of(seg, info[s].n_items, st[s]);
+        if ((rc = plan_pass2(seg, news, n_queries, st[s], info[s], tmp_base[s].data()))) {
+            if (seg != ix) ix->err = seg->err;
+            return rc;
+        }
+        HIP_TRY(ix, seg->q_items.ensure((size_t)std::max(info[s].n_items, 1u) * sizeof(QItem)));
+        HIP_TRY(ix, seg->q_terms.ensure(std::max<size_t>(info[s].n_flat, 1) * 4));
+        SearchBufs b{seg->q_items.as<QItem>(), seg->q_terms.as<uint32_t>(), nullptr, nullptr,
+                     ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
+                     ix->t_score.as<double>()};
+        if ((rc = score_segment(ix, seg, news, k, st[s], info[s], b, d_unit, d_score, d_mat, d_tie, d_count))) return rc;
+    }
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_first.p, first.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(ix, hipMemcpyAsync(ix->q_n.p, nlists.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
+    MergeArgs m{};
+    m.n_queries = n_queries; m.k = k;
+    m.first = ix->q_first.as<uint32_t>(); m.n = ix->q_n.as<uint32_t>();
+    m.in_unit = ix->t_unit.as<uint32_t>(); m.in_score = ix->t_score.as<double>(); m.in_matched = ix->t_mat.as<uint32_t>();
+    m.in_tie = ix->t_tie.as<uint32_t>(); m.in_count = ix->t_count.as<uint32_t>();
+    m.list_stride = 1;
+    m.out_unit = d_unit; m.out_score = d_score; m.out_matched = d_mat; m.out_tie = d_tie; m.out_count = d_count;
+    phase_begin(ix, "merge_slices");
+    launch_merge(m, ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));  // the host vectors above were the source of asynchronous copies
+    return SEBM25_OK;
+}
+
 int check_search_args(sebm25_index* ix, int source, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
                       uint32_t k, uint32_t max_k, const uint32_t* out_unit, const double* out_score,
                       const uint32_t* out_matched, const uint32_t* out_count) {
@@ -1049,20 +1522,15 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     const bool news = source == (int)SEBM25_SRC_NEWS;
 
     // ---- plan (host storage grown on demand)
-    SearchPlanVecs& v = ix->plan_vecs;
-    v.flat.resize(std::max<size_t>(q_offsets[n_queries], 1));
-    for (std::vector<uint32_t>* x : {&v.q_toff, &v.q_nt, &v.q_ns, &v.first, &v.nlists}) x->resize(n_queries);
-    v.q_len.resize(n_queries);
-    v.bucket.resize(plan_buckets() + 1);
+    const bool segmented = !ix->deltas.empty();
     PlanStore st{};
-    st.flat = v.flat.data(); st.flat_cap = v.flat.size();
-    st.q_toff = v.q_toff.data(); st.q_nt = v.q_nt.data(); st.q_ns = v.q_ns.data(); st.q_len = v.q_len.data();
-    st.first = v.first.data(); st.nlists = v.nlists.data(); st.bucket = v.bucket.data();
     PlanInfo info;
-    if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, ~0ull))) return rc;
-    v.items.resize(info.n_items); v.unsorted.resize(info.n_items); v.item_len.resize(info.n_items);
-    st.items = v.items.data(); st.unsorted = v.unsorted.data(); st.item_len = v.item_len.data(); st.item_cap = info.n_items;
-    if ((rc = plan_pass2(ix, news, n_queries, st, info))) return rc;
+    if (!segmented) {
+        plan_store_of(ix, q_offsets, n_queries, st);
+        if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, ~0ull))) return rc;
+        plan_items_of(ix, info.n_items, st);
+        if ((rc = plan_pass2(ix, news, n_queries, st, info))) return rc;
+    }
 
     // ---- device buffers
     const size_t qk = (size_t)n_queries * k, tk = (size_t)std::max(info.n_tmp, 1u) * k;
@@ -1098,7 +1566,11 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     SearchBufs b{ix->q_items.as<QItem>(), ix->q_terms.as<uint32_t>(), ix->q_first.as<uint32_t>(), ix->q_n.as<uint32_t>(),
                  ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
                  ix->t_score.as<double>()};
-    if ((rc = run_search(ix, news, n_queries, k, st, info, b, d_unit, d_score, d_mat, d_tie, d_count))) return rc;
+    if (segmented)
+        rc = search_segments(ix, news, q_terms, q_offsets, n_queries, k, d_unit, d_score, d_mat, d_tie, d_count);
+    else
+        rc = run_search(ix, news, n_queries, k, st, info, b, d_unit, d_score, d_mat, d_tie, d_count);
+    if (rc) return rc;
     if (!dev_out) {
         if ((rc = copy_out(ix, out_unit, d_unit, qk * 4))) return rc;
         if ((rc = copy_out(ix, out_score, d_score, qk * 8))) return rc;
@@ -1122,6 +1594,8 @@ int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms,
     if (rc || n_queries == 0) return rc;
     if (n_queries > NA_MAX_QUERIES)
         return fail(ix, SEBM25_E_RANGE, "search_noalloc: at most 1024 queries per call (use sebm25_search for larger batches)");
+    if (!ix->deltas.empty())
+        return fail(ix, SEBM25_E_STATE, "search_noalloc: the index has update segments (call sebm25_compact, or use sebm25_search)");
     if (ix->device >= NA_MAX_DEVICES || !g_na_ptr[ix->device] || !ix->na_host)
         return fail(ix, SEBM25_E_STATE, "search_noalloc: the fixed storage was not set up when the handle was created");
     if (!ix->host_ptrs_valid && (ix->h_row_ptr.size() != (size_t)ix->V + 1 || ix->h_news_ptr.size() != ix->V))

@@ -146,6 +146,19 @@ void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, double* idf, d
 void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_terms, double* idf_used,
                          hipStream_t st);
 
+// incremental update (update_kernels.hip)
+void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm, hipStream_t st);
+void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipStream_t st);
+void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
+                      const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      uint32_t* term_rows, unsigned long long* counts /* [4] */, hipStream_t st);
+void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
+                         uint32_t* err, hipStream_t st);
+void launch_doc_len_merge(uint32_t* doc_len, const uint32_t* new_len, const uint32_t* chg_web, uint32_t n_docs, hipStream_t st);
+void launch_add_u32(uint32_t* dst, const uint32_t* src, uint32_t n, hipStream_t st);
+void launch_gather_live(const uint64_t* rows, uint64_t R, RowFmt from, RowFmt to, const uint32_t* dead_web,
+                        const uint32_t* dead_news, uint64_t* out, unsigned long long* n_out, hipStream_t st);
+
 // scoring
 constexpr uint32_t SCORE_FAST_T = 4;  // queries of up to this many lists take the stepwise kernels
 struct QItem {

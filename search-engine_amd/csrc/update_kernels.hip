@@ -1,0 +1,150 @@
+// Kernels of the incremental update (sebm25_update / sebm25_compact).
+//
+// The reference keeps `tokens` current row by row: the crawler deletes a document's rows and inserts the new
+// ones (app/crawler/worker.py:229-239, app/batch/news_fetcher.py:303-311) and the statistics job recomputes
+// everything every BATCH_INTERVAL_S seconds (.env:11, app/batch/bm25_stats.py:15).  Here an update leaves the
+// index segments that exist alone except for marking, in each of them, the rows of the units that changed as
+// dead (their posting slots become holes, their terms' df / row counts go down), and builds the new rows of
+// those units into a segment of their own.  A unit's live rows are therefore always in exactly one segment.
+#include "common.hpp"
+
+namespace sebm25 {
+
+namespace {
+
+__device__ __forceinline__ bool bit_of(const uint32_t* bm, uint32_t i) { return (bm[i >> 5] >> (i & 31u)) & 1u; }
+
+// bits of the listed ids (ids >= n are ignored: a removed unit beyond the id space has no rows anywhere)
+__global__ void k_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ids && ids[i] < n) atomicOr(&bm[ids[i] >> 5], 1u << (ids[i] & 31u));
+}
+
+__global__ void k_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] |= src[i];
+}
+
+// One thread per sorted row of a segment.  A row whose unit changed in this update (and was alive here until
+// now) dies: its term loses a row; if it is the first row of its (term, source, unit) run and a web row, the
+// term loses a document (df counts web docs of any status); if its slot carried a posting, the slot becomes a
+// hole.  counts: [0] postings removed, [1] web postings removed, [2] web (term, doc) pairs removed, [3] rows.
+__global__ __launch_bounds__(256) void k_tombstone(const uint64_t* rows, uint32_t R, RowFmt fmt, const uint32_t* chg_web,
+                                                   const uint32_t* chg_news, const uint32_t* dead_web,
+                                                   const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                                                   uint32_t* term_rows, unsigned long long* counts) {
+    uint32_t c_post = 0, c_web = 0, c_head = 0, c_rows = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = rows[i];
+        const uint32_t src = fmt.src(r), unit = fmt.unit(r);
+        const bool dies = src ? (bit_of(chg_news, unit) && !bit_of(dead_news, unit)) : (bit_of(chg_web, unit) && !bit_of(dead_web, unit));
+        if (!dies) continue;
+        const uint32_t term = fmt.term(r);
+        atomicSub(&term_rows[term], 1u);
+        ++c_rows;
+        if (!src && (i == 0 || fmt.key(rows[i - 1]) != fmt.key(r))) {
+            atomicSub(&df[term], 1u);
+            ++c_head;
+        }
+        if (post_w[i] != POST_HOLE) {
+            post_w[i] = POST_HOLE;
+            ++c_post;
+            c_web += src ? 0u : 1u;
+        }
+    }
+    if (c_rows) {
+        atomicAdd(&counts[3], (unsigned long long)c_rows);
+        if (c_post) atomicAdd(&counts[0], (unsigned long long)c_post);
+        if (c_web) atomicAdd(&counts[1], (unsigned long long)c_web);
+        if (c_head) atomicAdd(&counts[2], (unsigned long long)c_head);
+    }
+}
+
+// every row of the new segment must belong to a unit that the update lists as changed
+__global__ __launch_bounds__(256) void k_check_listed(const uint64_t* rows, uint32_t R, RowFmt fmt, const uint32_t* chg_web,
+                                                      const uint32_t* chg_news, uint32_t* err) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = rows[i];
+        const uint32_t unit = fmt.unit(r);
+        if (!bit_of(fmt.src(r) ? chg_news : chg_web, unit)) atomicOr(err, DEV_ERR_RANGE);
+    }
+}
+
+// body length per doc after an update: the new segment's value for changed docs, the old value otherwise
+__global__ void k_doc_len_merge(uint32_t* doc_len, const uint32_t* new_len, const uint32_t* chg_web, uint32_t n_docs) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_docs && bit_of(chg_web, d)) doc_len[d] = new_len[d];
+}
+
+__global__ void k_add_u32(uint32_t* dst, const uint32_t* src, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// compaction: the live rows of one segment, repacked to the common row format, appended in any order
+__global__ __launch_bounds__(256) void k_gather_live(const uint64_t* rows, uint32_t R, RowFmt from, RowFmt to,
+                                                     const uint32_t* dead_web, const uint32_t* dead_news, uint64_t* out,
+                                                     unsigned long long* n_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull; i0 < R; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + lane;
+        uint64_t r = 0;
+        bool live = false;
+        if (i < R) {
+            r = rows[i];
+            const uint32_t src = from.src(r);
+            live = !bit_of(src ? dead_news : dead_web, from.unit(r));
+        }
+        const uint64_t m = __ballot(live);
+        if (!m) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+        base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+        if (live)
+            out[base + __popcll(m & ((1ull << lane) - 1ull))] = to.pack(from.term(r), from.src(r), from.unit(r), from.fc(r), from.tf(r));
+    }
+}
+
+}  // namespace
+
+static inline dim3 grid_for(uint64_t n, int threads, int cap = 8192) {
+    uint64_t g = (n + threads - 1) / threads;
+    return dim3((unsigned)(g < 1 ? 1 : (g > (uint64_t)cap ? (uint64_t)cap : g)));
+}
+
+void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm, hipStream_t st) {
+    if (n_ids == 0) return;
+    hipLaunchKernelGGL(k_bitmap_set, dim3((n_ids + 255) / 256), dim3(256), 0, st, ids, n_ids, n, bm);
+}
+void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipStream_t st) {
+    if (n_words == 0) return;
+    hipLaunchKernelGGL(k_bitmap_or, dim3((n_words + 255) / 256), dim3(256), 0, st, dst, src, n_words);
+}
+void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
+                      const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      uint32_t* term_rows, unsigned long long* counts, hipStream_t st) {
+    if (R == 0) return;
+    hipLaunchKernelGGL(k_tombstone, grid_for(R, 256), dim3(256), 0, st, rows, (uint32_t)R, fmt, chg_web, chg_news, dead_web,
+                       dead_news, post_w, df, term_rows, counts);
+}
+void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
+                         uint32_t* err, hipStream_t st) {
+    if (R == 0) return;
+    hipLaunchKernelGGL(k_check_listed, grid_for(R, 256), dim3(256), 0, st, rows, (uint32_t)R, fmt, chg_web, chg_news, err);
+}
+void launch_doc_len_merge(uint32_t* doc_len, const uint32_t* new_len, const uint32_t* chg_web, uint32_t n_docs, hipStream_t st) {
+    if (n_docs == 0) return;
+    hipLaunchKernelGGL(k_doc_len_merge, dim3((n_docs + 255) / 256), dim3(256), 0, st, doc_len, new_len, chg_web, n_docs);
+}
+void launch_add_u32(uint32_t* dst, const uint32_t* src, uint32_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_add_u32, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n);
+}
+void launch_gather_live(const uint64_t* rows, uint64_t R, RowFmt from, RowFmt to, const uint32_t* dead_web,
+                        const uint32_t* dead_news, uint64_t* out, unsigned long long* n_out, hipStream_t st) {
+    if (R == 0) return;
+    hipLaunchKernelGGL(k_gather_live, grid_for(R, 256), dim3(256), 0, st, rows, (uint32_t)R, from, to, dead_web, dead_news, out,
+                       n_out);
+}
+
+}  // namespace sebm25

@@ -94,6 +94,96 @@ class SearchEngine:
                 old.close()
             return st
 
+    # ---- incremental: what changed since the last build, instead of the whole table again
+    COMPACT_SEGMENTS = 8        # fold the update segments into one beyond this many ...
+    COMPACT_DEAD_FRACTION = 0.25  # ... or when this share of the held rows is dead
+
+    def update(self, doc_ids=(), article_urls=(), write_back: bool = True) -> dict:
+        """Brings the index (and term_statistics) to the state a rebuild would give after the crawler replaced,
+        removed or added the given documents (documents.id) and news articles (url): their current rows are
+        read from the database, everything the index held for them is dropped (app/crawler/worker.py:229-239,
+        app/batch/news_fetcher.py:303-311).  Only these units' rows cross to the GPU."""
+        self.ensure_ready()
+        with self._build_lock:
+            ex, ix = self.export, self.index
+            data = self.store.export_units(ex, doc_ids, article_urls)
+            if getattr(self, "_doc_pos", None) is None or self._pos_of is not ex:
+                self._doc_pos = {int(d): i for i, d in enumerate(ex.doc_ids.tolist())}
+                self._art_pos = {u: i for i, u in enumerate(ex.article_urls)}
+                self._pos_of = ex
+            doc_pos, art_pos = self._doc_pos, self._art_pos
+            with self._lock:
+                # ---- documents: position of each changed id (new ids go to the end), columns as they are now
+                doc_ids_l = ex.doc_ids.tolist()
+                wc, fl, urls = ex.word_count.tolist(), ex.doc_flags.tolist(), ex.doc_urls
+                changed_docs = []
+                for d in dict.fromkeys(int(x) for x in doc_ids):
+                    row = data["docs"].get(d)
+                    if d not in doc_pos:
+                        if row is None:
+                            continue                       # never indexed and not there now
+                        doc_pos[d] = len(doc_ids_l)
+                        doc_ids_l.append(d)
+                        wc.append(0)
+                        fl.append(0)
+                        urls.append(None)
+                    i = doc_pos[d]
+                    changed_docs.append(i)
+                    if row is None:                        # the document is gone
+                        wc[i], fl[i], urls[i] = 0, 0, None
+                    else:
+                        url, w, status = row
+                        wc[i] = int(w or 0)
+                        fl[i] = (1 if status == "done" else 0) | (2 if w is None else 0)
+                        urls[i] = url
+                changed_arts = []
+                for u in dict.fromkeys(article_urls):
+                    if u not in art_pos:
+                        if u not in data["articles"]:
+                            continue
+                        art_pos[u] = len(ex.article_urls)
+                        ex.article_urls.append(u)
+                    changed_arts.append(art_pos[u])
+                # ---- rows of these units, terms through the dictionary (new terms go to the end)
+                ti = ex.term_index
+                t_l, u_l, f_l, m_l = [], [], [], []
+                for d, term, fld, freq in data["doc_rows"]:
+                    if int(d) in doc_pos:
+                        t_l.append(ti.setdefault(term, len(ti)))
+                        u_l.append(doc_pos[int(d)])
+                        f_l.append(max(int(freq), 0))
+                        m_l.append(1 | ((int(fld) & 63) << 2))
+                for url, term, fld, freq in data["article_rows"]:
+                    if url in art_pos and url in data["articles"]:
+                        t_l.append(ti.setdefault(term, len(ti)))
+                        u_l.append(art_pos[url])
+                        f_l.append(max(int(freq), 0))
+                        m_l.append(2 | ((int(fld) & 63) << 2))
+                if len(ti) > len(ex.terms):
+                    ex.terms.extend(list(ti)[len(ex.terms):])
+                ex.doc_ids = np.asarray(doc_ids_l, np.int64)
+                ex.word_count = np.asarray(wc, np.uint32)
+                ex.doc_flags = np.asarray(fl, np.uint8)
+                ix.update(np.asarray(t_l, np.uint32), np.asarray(u_l, np.uint32), np.asarray(f_l, np.uint32),
+                          np.asarray(m_l, np.uint8), ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count, ex.doc_flags,
+                          changed_docs=changed_docs, changed_articles=changed_arts)
+                if ex.n_docs:
+                    ix.set_url_rank(SRC_WEB, url_ranks(ex.doc_urls, self._collation_key))
+                if ex.n_articles:      # appended articles are no longer in url order: explicit ranks
+                    ix.set_url_rank(SRC_NEWS, url_ranks(ex.article_urls, self._collation_key))
+                inf = ix.info() if hasattr(ix, "info") else None
+                if inf is not None and (inf.n_segments > self.COMPACT_SEGMENTS or
+                                        inf.n_dead_rows > self.COMPACT_DEAD_FRACTION * max(inf.n_rows + inf.n_dead_rows, 1)):
+                    ix.compact()
+                st = ix.stats()
+            if write_back:
+                self.store.write_term_statistics(ex.terms, st["df"], st["idf"], st["avgdl"], st["term_rows"], ex.extra_term_rows)
+            self.table_version = self.store.term_statistics_version()
+            if self.idf_source == "table":
+                with self._lock:
+                    self._apply_table_idf(ix, ex)
+            return st
+
     def refresh(self) -> dict:
         """Rebuilds this process's index from the database without touching term_statistics."""
         return self.rebuild(write_back=False)

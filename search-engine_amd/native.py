@@ -52,6 +52,7 @@ class IndexInfo(C.Structure):
         ("n_rows", C.c_uint64), ("n_postings", C.c_uint64), ("n_web_postings", C.c_uint64),
         ("n_terms", C.c_uint32), ("n_docs", C.c_uint32), ("n_articles", C.c_uint32),
         ("term_bits", C.c_uint32), ("unit_bits", C.c_uint32), ("tf_bits", C.c_uint32), ("sort_passes", C.c_uint32),
+        ("n_segments", C.c_uint32), ("n_dead_rows", C.c_uint64),
     ]
 
 
@@ -66,7 +67,7 @@ class CorpusSpec(C.Structure):
 # every symbol include/sebm25.h declares
 EXPORTS = [
     "sebm25_create", "sebm25_destroy", "sebm25_last_error", "sebm25_set_stream", "sebm25_build_local",
-    "sebm25_local_stats", "sebm25_finalize", "sebm25_build", "sebm25_get_stats", "sebm25_get_doc_len",
+    "sebm25_local_stats", "sebm25_finalize", "sebm25_build", "sebm25_update", "sebm25_update_local", "sebm25_compact", "sebm25_get_stats", "sebm25_get_doc_len",
     "sebm25_set_idf", "sebm25_set_url_rank", "sebm25_set_unit_base", "sebm25_get_info", "sebm25_get_postings",
     "sebm25_search", "sebm25_search_noalloc", "sebm25_merge_topk", "sebm25_get_timings", "sebm25_enable_timing", "sebm25_zipf_cdf",
     "sebm25_gen_corpus", "sebm25_gen_queries",
@@ -104,6 +105,9 @@ def lib():
     L.sebm25_local_stats.argtypes = [vp, vp, C.POINTER(DocTotals)]
     L.sebm25_finalize.argtypes = [vp, vp, C.POINTER(DocTotals)]
     L.sebm25_build.argtypes = [vp, C.POINTER(Rows)]
+    L.sebm25_update.argtypes = [vp, C.POINTER(Rows), vp, u32, vp, u32]
+    L.sebm25_update_local.argtypes = [vp, C.POINTER(Rows), vp, u32, vp, u32]
+    L.sebm25_compact.argtypes = [vp]
     L.sebm25_get_stats.argtypes = [vp, vp, vp, vp, C.POINTER(u64), C.POINTER(C.c_double)]
     L.sebm25_get_doc_len.argtypes = [vp, vp]
     L.sebm25_set_idf.argtypes = [vp, vp, vp]
@@ -234,21 +238,43 @@ class Index:
         for x in (unit_id, tf, meta_):
             if (int(x.shape[0]) if x is not None else 0) != n:
                 raise ValueError("row arrays must have equal length")
-        self.n_terms, self.n_docs, self.n_articles = int(n_terms), int(n_docs), int(n_articles)
-        return Rows(_addr(term_id), _addr(unit_id), _addr(tf), _addr(meta_), n, self.n_terms, self.n_docs,
-                    self.n_articles, _addr(word_count), _addr(doc_flags), ROWS_UNIT_MAJOR if unit_major else 0)
+        return Rows(_addr(term_id), _addr(unit_id), _addr(tf), _addr(meta_), n, int(n_terms), int(n_docs),
+                    int(n_articles), _addr(word_count), _addr(doc_flags), ROWS_UNIT_MAJOR if unit_major else 0)
+
+    def _built(self, r: Rows):
+        # sizes of the output arrays of stats() / doc_len() / postings(): only what the library accepted
+        self.n_terms, self.n_docs, self.n_articles = int(r.n_terms), int(r.n_docs), int(r.n_articles)
 
     def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
               unit_major=True):
         """The whole statistics job on one GPU (sort, CSR, df, totals, idf)."""
         r = self._rows(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major)
         self._check(self._L.sebm25_build(self._h, C.byref(r)))
+        self._built(r)
 
     def build_local(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
                     unit_major=True):
         """This shard's part of the job; follow with local_stats -> (sum across shards) -> finalize."""
         r = self._rows(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major)
         self._check(self._L.sebm25_build_local(self._h, C.byref(r)))
+        self._built(r)
+
+    def update(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
+               changed_docs=None, changed_articles=None, unit_major=False, local=False):
+        """Incremental update (sebm25_update): the listed units lose every row the index holds for them and get
+        the rows given here; n_terms / n_docs / n_articles and word_count / doc_flags describe the tables as they
+        are now.  local=True leaves the statistics to a following local_stats / finalize (sharded indexes)."""
+        r = self._rows(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major)
+        cd = np.ascontiguousarray(changed_docs if changed_docs is not None else [], np.uint32)
+        ca = np.ascontiguousarray(changed_articles if changed_articles is not None else [], np.uint32)
+        fn = self._L.sebm25_update_local if local else self._L.sebm25_update
+        self._check(fn(self._h, C.byref(r), cd.ctypes.data if len(cd) else None, len(cd),
+                       ca.ctypes.data if len(ca) else None, len(ca)))
+        self._built(r)
+
+    def compact(self):
+        """Folds the update segments into one (sebm25_compact); results do not change."""
+        self._check(self._L.sebm25_compact(self._h))
 
     def local_stats(self, df_out=None):
         """-> (df, DocTotals).  df_out may be a preallocated numpy array / torch tensor."""

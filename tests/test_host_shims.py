@@ -65,7 +65,10 @@ class OracleBackedIndex:
     """native.Index look-alike on the CPU oracle: lets the host logic run without a GPU."""
 
     def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, unit_major=True):
-        self.orc = O.OracleIndex(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags)
+        self.rows = [np.array(term_id, np.uint32), np.array(unit_id, np.uint32), np.array(tf, np.uint32), np.array(meta, np.uint8)]
+        order = np.lexsort((self.rows[1], self.rows[3] & 3))        # the oracle takes unit-major rows
+        self.rows = [a[order] for a in self.rows]
+        self.orc = O.OracleIndex(*self.rows, n_terms, n_docs, n_articles, word_count, doc_flags)
         self.rank = {1: None, 2: None}
 
     def stats(self):
@@ -87,6 +90,16 @@ class OracleBackedIndex:
             n = len(u)
             out["unit"][i, :n], out["score"][i, :n], out["matched"][i, :n], out["count"][i] = u, s, m, n
         return out
+
+    def update(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, changed_docs=(),
+               changed_articles=(), **kw):
+        # the stand-in has no segments: it drops the changed units' rows from its copy of the table and rebuilds
+        o = self.rows
+        src = o[3] & 3
+        dead = ((src == 1) & np.isin(o[1], np.asarray(changed_docs, np.uint32))) | \
+               ((src == 2) & np.isin(o[1], np.asarray(changed_articles, np.uint32)))
+        rows = [np.concatenate([a[~dead], np.asarray(b, a.dtype)]) for a, b in zip(o, (term_id, unit_id, tf, meta))]
+        self.build(*rows, n_terms, n_docs, n_articles, word_count, doc_flags)
 
     def close(self):
         pass
@@ -399,3 +412,61 @@ def test_url_ranks():
     assert r.tolist() == [1, 0, 2]
     r = url_ranks(["B", "a", "C"], key=str.lower)
     assert r.tolist() == [1, 0, 2]
+
+
+def check_engine_update(tmp_path, index_factory):
+    """Crawler-style changes applied through SearchEngine.update: term_statistics and search rows equal what the
+    reference's statements give on the changed database."""
+    path = str(tmp_path / "se.db")
+    make_db(path)
+    store = SqlStore(lambda: sqlite3.connect(path))
+    engine = SearchEngine(store, index_factory=index_factory)
+    engine.rebuild()
+    db = sqlite3.connect(path)
+    # doc 12 re-crawled with new text, doc 15 removed, doc 21 finished, a new doc 40, a new article, article a2 removed
+    def put_doc(doc_id, url, title, desc, content, status="done"):
+        db.execute("DELETE FROM tokens WHERE doc_id = ?", (doc_id,))                     # worker.py:229
+        db.execute("INSERT OR REPLACE INTO documents VALUES (?,?,?,?,?,?,?)", (doc_id, url, title, desc, content, len(content.split()), status))
+        for field, text in ((1, title), (2, desc), (4, content)):
+            for term, freq in tokenize(text or "").items():
+                db.execute("INSERT INTO tokens VALUES (?,?,?,?,NULL,1)", (doc_id, term, field, freq))
+    put_doc(12, "https://gpu.example/bm25", "BM25 and radix", "Ranking with radix sorted postings", "ranking bm25 radix sort postings quantum")
+    db.execute("DELETE FROM tokens WHERE doc_id = 15")
+    db.execute("DELETE FROM documents WHERE id = 15")
+    put_doc(21, "https://gpu.example/draft", "Radix draft", "finished now", "radix radix radix sort")
+    put_doc(40, "https://aaa.example/first", "Sorting radix keys", "", "radix sort keys quantum")
+    db.execute("INSERT INTO news_articles VALUES ('https://news.example/a0','https://news.example/feed','Quantum radix','',NULL,'quantum radix sort','Bo',NULL)")
+    for term, freq in tokenize("Quantum radix quantum radix sort").items():
+        db.execute("INSERT INTO tokens VALUES (NULL,?,4,?,'https://news.example/a0',2)", (term, freq))
+    db.execute("DELETE FROM tokens WHERE article_url = 'https://news.example/a2'")
+    db.execute("DELETE FROM news_articles WHERE url = 'https://news.example/a2'")
+    db.commit()
+    db.close()
+    engine.update(doc_ids=[12, 15, 21, 40, 999], article_urls=["https://news.example/a0", "https://news.example/a2"])
+    db = sqlite3.connect(path)
+    got = {t: (df, idf) for t, df, idf, _ in db.execute("SELECT * FROM term_statistics")}
+    n_done = db.execute("SELECT COUNT(*) FROM documents WHERE status='done'").fetchone()[0]
+    want = db.execute("SELECT term, COUNT(DISTINCT doc_id) FROM tokens GROUP BY term").fetchall()
+    db.close()
+    assert set(got) == {t for t, _ in want} and "quantum" in got
+    for term, df in want:
+        assert got[term][0] == df, term
+        assert got[term][1] == pytest.approx(math.log((n_done - df + 0.5) / (df + 0.5) + 1), rel=1e-14)
+    for terms in (["radix", "sort"], ["quantum"], ["rank", "bm25", "post"]):
+        rows, ref = engine.score_web(terms, 50), sql_reference_rows(path, terms, 50)
+        assert [r[:3] for r in rows] == [r[:3] for r in ref] and [r[4] for r in rows] == [r[4] for r in ref], terms
+        np.testing.assert_allclose([r[3] for r in rows], [r[3] for r in ref], rtol=1e-12)
+    news = engine.score_news(["radix", "quantum"], 50)
+    assert [r[2] for r in news] == ["https://news.example/a0", "https://news.example/a1"]
+    return engine
+
+
+def test_engine_update_on_cpu_stand_in(tmp_path):
+    check_engine_update(tmp_path, OracleBackedIndex)
+
+
+@pytest.mark.gpu
+def test_engine_update_on_gpu(tmp_path):
+    engine = check_engine_update(tmp_path, None)
+    assert engine.index.info().n_segments in (1, 2)      # a tiny index crosses the dead-row threshold and is compacted at once
+    engine.index.close()
