@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-query", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the flag-less / rank-less comparison runs")
+    ap.add_argument("--no-update", action="store_true", help="skip the incremental-update leg")
+    ap.add_argument("--update-docs", type=int, default=1000, help="docs re-crawled per incremental update")
     return ap.parse_args()
 
 
@@ -338,6 +340,42 @@ def main():
         out["variant_without_doc_flags"] = {"device_ms_sum_of_phases": sum(ph2.values()),
                                             "sort_scatter_0_ms": ph2.get("sort_scatter_0"),
                                             "note": "doc_flags = NULL: the first sort pass reads no status bytes"}
+
+    # ---- incremental update: a crawl cycle's worth of re-crawled docs applied to the built index
+    if world == 1 and not args.no_update:
+        upd_docs = min(args.update_docs, docs // 8)
+        times, rows_u = [], 0
+        step()                                             # a fresh base segment
+        for i in range(4):
+            a = (i * 2 + 1) * docs // 9                    # docs [a, a + upd_docs) are crawled again with new text
+            spec = se.make_spec(seed=777 + i, n_terms=V, n_docs=upd_docs, doc_begin=a)
+            n_u = ix.gen_corpus_rows(spec)
+            u = dict(term=torch.empty(n_u, dtype=torch.int32, device=dev), unit=torch.empty(n_u, dtype=torch.int32, device=dev),
+                     tf=torch.empty(n_u, dtype=torch.int32, device=dev), meta=torch.empty(n_u, dtype=torch.uint8, device=dev),
+                     wc=torch.empty(upd_docs, dtype=torch.int32, device=dev))
+            ix.gen_corpus(spec, u["term"], u["unit"], u["tf"], u["meta"], u["wc"])
+            u["unit"] += a                                 # generated ids are local to the range
+            c["wc"][a:a + upd_docs] = u["wc"]
+            changed = np.arange(a, a + upd_docs, dtype=np.uint32)
+            sync()
+            t0 = time.perf_counter()
+            ix.update(u["term"], u["unit"], u["tf"], u["meta"], V, docs, args.articles, c["wc"], c["flags"], changed_docs=changed,
+                      unit_major=True)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+            rows_u = n_u
+        inf_u = ix.info()
+        sync()
+        t0 = time.perf_counter()
+        ix.compact()
+        torch.cuda.synchronize()
+        compact_ms = (time.perf_counter() - t0) * 1e3
+        out["incremental_update"] = {
+            "docs_per_update": upd_docs, "rows_per_update": int(rows_u), "ms_per_update": statistics.median(times),
+            "ms_each": [round(t, 3) for t in times], "full_build_ms": median_ms,
+            "segments_after": int(inf_u.n_segments), "dead_rows_after": int(inf_u.n_dead_rows), "compact_ms": compact_ms,
+            "note": "sebm25_update of re-crawled docs on the configuration-2 index (rows resident in HBM), then sebm25_compact "
+                    "of the base + 4 update segments; correctness of both is covered by tests/test_gpu_update.py"}
 
     # ---- batched scoring
     if not args.no_query:

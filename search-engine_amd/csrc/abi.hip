@@ -756,27 +756,38 @@ int do_compact(sebm25_index* ix) {
     for (sebm25_index* g : segs)
         if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
     // ---- the live rows of every segment, in the common row format, into a new sort buffer
+    // The base segment's sorted rows sit in one of its two sort buffers and its posting slots in the other; the
+    // slots are rebuilt anyway, so their buffer takes the gathered rows when it is large enough (no allocation).
     const size_t cap = std::max<uint64_t>(total, 1);
+    const size_t need = (cap + POST_PAD) * 8;
+    DevBuf* slot_buf = ix->sorted_rows == ix->sortA.as<uint64_t>() ? &ix->sortB : &ix->sortA;
     DevBuf nA;
-    HIP_TRY(ix, nA.ensure((cap + POST_PAD) * 8));
+    const bool in_place = ix->sorted_rows && slot_buf->cap >= need;
+    if (!in_place) HIP_TRY(ix, nA.ensure(need));
+    uint64_t* gathered = in_place ? slot_buf->as<uint64_t>() : nA.as<uint64_t>();
     HIP_TRY(ix, ix->upd_counts.ensure(64));
     hipError_t e = hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream);
     for (sebm25_index* g : segs)
         launch_gather_live(g->sorted_rows, g->R, g->fmt, fmt, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(),
-                           nA.as<uint64_t>(), ix->upd_counts.as<unsigned long long>(), ix->stream);
+                           gathered, ix->upd_counts.as<unsigned long long>(), ix->stream);
     unsigned long long n_live = 0;
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&n_live, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     if (e != hipSuccess || n_live != total) {
         nA.release();
+        ix->built = ix->built && !in_place;  // the slots of the base segment were overwritten
         if (e != hipSuccess) HIP_TRY(ix, e);
         return fail(ix, SEBM25_E_INTERNAL, "compact: live row count disagrees with the segments' bookkeeping");
     }
-    // ---- from here on the handle is the one new segment
+    // ---- from here on the handle is the one new segment, its rows in sort buffer A
     drop_deltas(ix);
-    ix->sortA.release();
-    ix->sortA = nA;
+    if (in_place) {
+        if (slot_buf == &ix->sortB) std::swap(ix->sortA, ix->sortB);
+    } else {
+        ix->sortA.release();
+        ix->sortA = nA;
+    }
     ix->R = n_live; ix->V = ix->V_cur; ix->n_docs = ix->n_docs_cur; ix->n_articles = ix->n_articles_cur; ix->fmt = fmt;
     ix->has_dead = false;
     ix->dead_rows = 0;

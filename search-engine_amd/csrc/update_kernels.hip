@@ -81,27 +81,43 @@ __global__ void k_add_u32(uint32_t* dst, const uint32_t* src, uint32_t n) {
     if (i < n) dst[i] += src[i];
 }
 
-// compaction: the live rows of one segment, repacked to the common row format, appended in any order
+// compaction: the live rows of one segment, repacked to the common row format, appended in any order.  One
+// wavefront takes spans of GATHER_SPAN consecutive rows: it counts the live ones, reserves their places with one
+// atomic (appends to one counter are served one at a time, so they must be few), then reads the span again and
+// writes.
+constexpr uint32_t GATHER_SPAN = 64 * 32;
 __global__ __launch_bounds__(256) void k_gather_live(const uint64_t* rows, uint32_t R, RowFmt from, RowFmt to,
                                                      const uint32_t* dead_web, const uint32_t* dead_news, uint64_t* out,
                                                      unsigned long long* n_out) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull; i0 < R; i0 += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = i0 + lane;
-        uint64_t r = 0;
-        bool live = false;
-        if (i < R) {
-            r = rows[i];
-            const uint32_t src = from.src(r);
-            live = !bit_of(src ? dead_news : dead_web, from.unit(r));
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t s0 = wave * GATHER_SPAN; s0 < R; s0 += n_waves * GATHER_SPAN) {
+        uint32_t n_live = 0;
+        for (uint32_t j = 0; j < GATHER_SPAN; j += 64) {
+            const uint64_t i = s0 + j + lane;
+            bool live = false;
+            if (i < R) {
+                const uint64_t r = rows[i];
+                live = !bit_of(from.src(r) ? dead_news : dead_web, from.unit(r));
+            }
+            n_live += (uint32_t)__popcll(__ballot(live));
         }
-        const uint64_t m = __ballot(live);
-        if (!m) continue;
+        if (n_live == 0) continue;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-        base = ((unsigned long long)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
-        if (live)
-            out[base + __popcll(m & ((1ull << lane) - 1ull))] = to.pack(from.term(r), from.src(r), from.unit(r), from.fc(r), from.tf(r));
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)n_live);
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+        for (uint32_t j = 0; j < GATHER_SPAN; j += 64) {
+            const uint64_t i = s0 + j + lane;
+            uint64_t r = 0;
+            bool live = false;
+            if (i < R) {
+                r = rows[i];
+                live = !bit_of(from.src(r) ? dead_news : dead_web, from.unit(r));
+            }
+            const uint64_t m = __ballot(live);
+            if (live) out[base + __popcll(m & ((1ull << lane) - 1ull))] = to.pack(from.term(r), from.src(r), from.unit(r), from.fc(r), from.tf(r));
+            base += (unsigned long long)__popcll(m);
+        }
     }
 }
 
