@@ -36,6 +36,24 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, ui
     return ka > kb || (ka == kb && ta < tb);
 }
 
+// value of lane (l ^ MASK): lane-exchange forms that stay in the vector pipeline where the hardware has one
+// (quad permutes, row mirrors), a swizzle for the 16 / 31 patterns, the LDS crossbar only across the wave halves
+template <uint32_t MASK>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    auto dpp = [](uint32_t x, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xF, 0xF, false); };
+    using std::integral_constant;
+    if constexpr (MASK == 1) return dpp(v, integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return dpp(v, integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) return dpp(v, integral_constant<int, 0x1B>{});   // quad_perm [3,2,1,0]
+    else if constexpr (MASK == 7) return dpp(v, integral_constant<int, 0x141>{});  // row_half_mirror
+    else if constexpr (MASK == 15) return dpp(v, integral_constant<int, 0x140>{}); // row_mirror
+    else if constexpr (MASK == 4) return dpp(dpp(v, integral_constant<int, 0x141>{}), integral_constant<int, 0x1B>{});   // ^7 then ^3
+    else if constexpr (MASK == 8) return dpp(dpp(v, integral_constant<int, 0x140>{}), integral_constant<int, 0x141>{});  // ^15 then ^7
+    else if constexpr (MASK == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+    else if constexpr (MASK == 31) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x7C1F);
+    else return (uint32_t)__shfl_xor((int)v, (int)MASK);
+}
+
 // Candidate buffer of one wave (LDS) for k up to S = CAP - 64.  Slots [0, S) hold the best candidates
 // seen so far, sorted best first (dead slots hold the worst key); slots [S, S + 64) collect new
 // candidates.  When those 64 are full, cut() sorts them in registers (a 64-lane bitonic network of
@@ -105,28 +123,31 @@ struct TopK {
             uint32_t uu = live ? unit[S + lane] : 0xFFFFFFFFu;
             uint32_t tt = HAS_TIE ? (live ? tie_[S + lane] : 0xFFFFFFFFu) : uu;
             uint32_t mm = live ? mat[S + lane] : 0u;
-            auto exchange = [&](uint32_t mask, uint32_t top) {  // partner = lane ^ mask; top = highest bit of mask
-                const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)kk, (int)mask);
-                const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(kk >> 32), (int)mask);
-                const uint32_t pu = (uint32_t)__shfl_xor((int)uu, (int)mask);
-                const uint32_t pt = HAS_TIE ? (uint32_t)__shfl_xor((int)tt, (int)mask) : pu;
-                const uint32_t pmat = (uint32_t)__shfl_xor((int)mm, (int)mask);
-                const uint64_t pk = ((uint64_t)phi << 32) | plo;
-                const bool lower = (lane & top) == 0u;
-                const bool partner_better = better(pk, pt, kk, tt), mine_better = better(kk, tt, pk, pt);
-                if (lower ? partner_better : mine_better) {  // the lower lane keeps the better entry
-                    kk = pk;
-                    uu = pu;
-                    tt = pt;
-                    mm = pmat;
-                }
-            };
-#pragma unroll
-            for (uint32_t lg = 1; lg <= 6; ++lg) {
-                exchange((1u << lg) - 1u, 1u << (lg - 1u));  // mirror stage
-#pragma unroll
-                for (uint32_t stride = 1u << (lg - 1u) >> 1; stride > 0; stride >>= 1) exchange(stride, stride);
+            // one compare-exchange stage: partner = lane ^ MASK, TOP = highest bit of MASK
+#define SEBM25_EXCHANGE(MASK, TOP)                                                                       \
+            {                                                                                             \
+                const uint32_t plo = lane_xor<MASK>((uint32_t)kk), phi = lane_xor<MASK>((uint32_t)(kk >> 32)); \
+                const uint32_t pu = lane_xor<MASK>(uu);                                                   \
+                const uint32_t pt = HAS_TIE ? lane_xor<MASK>(tt) : pu;                                    \
+                const uint32_t pmat = lane_xor<MASK>(mm);                                                 \
+                const uint64_t pk = ((uint64_t)phi << 32) | plo;                                          \
+                const bool lower = (lane & (TOP)) == 0u;                                                  \
+                const bool partner_better = better(pk, pt, kk, tt), mine_better = better(kk, tt, pk, pt); \
+                if (lower ? partner_better : mine_better) { /* the lower lane keeps the better entry */    \
+                    kk = pk;                                                                              \
+                    uu = pu;                                                                              \
+                    tt = pt;                                                                              \
+                    mm = pmat;                                                                            \
+                }                                                                                         \
             }
+            // bitonic sort of 64 lanes: per level a mirror stage, then half-cleaners of falling stride
+            SEBM25_EXCHANGE(1, 1)
+            SEBM25_EXCHANGE(3, 2) SEBM25_EXCHANGE(1, 1)
+            SEBM25_EXCHANGE(7, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
+            SEBM25_EXCHANGE(15, 8) SEBM25_EXCHANGE(4, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
+            SEBM25_EXCHANGE(31, 16) SEBM25_EXCHANGE(8, 8) SEBM25_EXCHANGE(4, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
+            SEBM25_EXCHANGE(63, 32) SEBM25_EXCHANGE(16, 16) SEBM25_EXCHANGE(8, 8) SEBM25_EXCHANGE(4, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
+#undef SEBM25_EXCHANGE
             key[S + lane] = kk;
             unit[S + lane] = uu;
             if (HAS_TIE) tie_[S + lane] = tt;
@@ -462,7 +483,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     constexpr uint32_t STEP_SLOTS = SLOTS, STEP_LIMIT = SLOTS - 64;
     static_assert((SLOTS & (SLOTS - 1)) == 0 && T * 64 <= (int)STEP_LIMIT, "the table never fills");
     __shared__ uint32_t tag[STEP_SLOTS];
-    __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * 4];  // per slot and list: weight in tenths + 1
+#ifdef SEBM25_WF4
+    constexpr uint32_t WF = 4;
+#else
+    constexpr uint32_t WF = T == 3 ? 4 : T;  // fields per slot: a slot's fields are read and cleared as one word
+#endif
+    __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * WF];  // per slot and list: weight in tenths + 1
     __shared__ unsigned short used[STEP_LIMIT + 64];
     __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
 
@@ -527,10 +553,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         load_block(t, pos[t], cur, u[t], w[t]);
         load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
     }
-    for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS; x += 64) {
-        tag[x] = HASH_EMPTY;
-        *reinterpret_cast<uint64_t*>(&wfield[x * 4u]) = 0ull;
-    }
+    for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS; x += 64) tag[x] = HASH_EMPTY;
+    for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS * WF; x += 64) wfield[x] = 0;
     TK tk;
     tk.init(topk_mem);
     uint32_t n_used = 0;
@@ -602,7 +626,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                                 if (tg == HASH_EMPTY) break;
                                 h = (h + 1u) & (STEP_SLOTS - 1u);
                             }
-                            if (found) wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
+                            if (found) wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                             if (old == un) break;
                             h = (h + 1u) & (STEP_SLOTS - 1u);
                         }
-                        wfield[h * 4u + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
+                        wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                     }
                     const uint64_t fm = __ballot(fresh);
                     if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
@@ -664,9 +688,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             if (has) {
                 const uint32_t h = used[n_used + lane];
                 unit = tag[h];
-                const uint64_t f = *reinterpret_cast<const uint64_t*>(&wfield[h * 4u]);
+                uint64_t f;
+                if constexpr (WF == 4) {
+                    f = *reinterpret_cast<const uint64_t*>(&wfield[h * 4u]);
+                    *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = 0ull;
+                } else if constexpr (WF == 2) {
+                    f = *reinterpret_cast<const uint32_t*>(&wfield[h * 2u]);
+                    *reinterpret_cast<uint32_t*>(&wfield[h * 2u]) = 0u;
+                } else {
+                    f = wfield[h];
+                    wfield[h] = 0;
+                }
                 tag[h] = HASH_EMPTY;
-                *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = 0ull;
 #pragma unroll
                 for (int j = 0; j < T; ++j) {  // the order the caller gave the terms in
                     const uint32_t ft = (uint32_t)(f >> sh[j]) & 0xFFFFu;

@@ -73,14 +73,15 @@ class SearchEngine:
     # ---- the statistics job: replaces the SQL of app/batch/bm25_stats.py:9-27
     def rebuild(self, write_back: bool = True) -> dict:
         with self._build_lock:
-            ex = self.store.export_tokens(alloc=_pinned_alloc() if self._native else None)
+            ex = self.store.export_tokens(alloc=_pinned_alloc() if self._native else None, collation_key=self._collation_key)
             ix = self._factory()
             ix.build(ex.term_id, ex.unit_id, ex.tf, ex.meta, ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count,
                      ex.doc_flags, unit_major=ex.unit_major)
             st = ix.stats()
-            if ex.n_docs:
+            # docs and articles are numbered in url order by the export: a unit's index is its ORDER BY url rank, which
+            # is the index's default tie-break key (no rank array, no gather per candidate)
+            if ex.n_docs and not ex.url_ordered:
                 ix.set_url_rank(SRC_WEB, url_ranks(ex.doc_urls, self._collation_key))
-            # articles are exported in url order already: their index is their rank
             if write_back:
                 self.store.write_term_statistics(ex.terms, st["df"], st["idf"], st["avgdl"], st["term_rows"],
                                                  ex.extra_term_rows)

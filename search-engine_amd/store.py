@@ -58,6 +58,9 @@ class TokenExport:
     # rows that reach no unit (a news row whose article is gone): the statistics job still groups them by
     # term (bm25_stats.py:23-24 reads `tokens` alone), so their terms get a term_statistics row
     extra_term_rows: np.ndarray | None = None
+    # dense doc indices were handed out in ascending url order: a doc's index is its ORDER BY url ASC rank,
+    # so the index needs no separate rank array for web ties
+    url_ordered: bool = False
 
     @property
     def n_terms(self):
@@ -174,7 +177,7 @@ class _Assembler:
             term_id, unit, tf, meta = term_id[keep], unit[keep], tf[keep], meta[keep]
         self.parts.append((term_id, unit, tf.astype(np.uint32), meta))
 
-    def finish(self, docs_word_count, docs_flags, doc_urls, article_urls, alloc) -> TokenExport:
+    def finish(self, docs_word_count, docs_flags, doc_urls, article_urls, alloc, collation_key=None) -> TokenExport:
         R = sum(len(p[0]) for p in self.parts)
         term_id = alloc(R, np.uint32)
         unit_id = alloc(R, np.uint32)
@@ -200,9 +203,13 @@ class _Assembler:
                 urls2[p] = doc_urls[i]
             remap = (old_pos, all_ids)
             doc_ids, word_count, doc_flags, doc_urls = all_ids, wc2, fl2, urls2
+        # dense doc index = rank of the doc's url (search ties break on url ASC: search_service.py:38)
+        doc_urls = list(doc_urls)
+        url_rank = url_ranks(doc_urls, collation_key).astype(np.int64)
+        by_rank = np.argsort(url_rank, kind="stable")
+        doc_ids, word_count, doc_flags = doc_ids[by_rank], word_count[by_rank], doc_flags[by_rank]
+        doc_urls = [doc_urls[i] for i in by_rank.tolist()]
         o = 0
-        ordered = True
-        last_key = -1
         for t_id, unit, tf_c, meta_c in self.parts:
             n = len(t_id)
             if n == 0:
@@ -216,20 +223,25 @@ class _Assembler:
                 uw2[~known] = np.searchsorted(remap[1], -1 - uw[~known])
                 unit = unit.copy()
                 unit[web] = uw2
+            web = (meta_c & 3) == 1
+            if web.any():
+                if web.all():
+                    unit = url_rank[unit]
+                else:
+                    unit = unit.copy()
+                    unit[web] = url_rank[unit[web]]
             term_id[o:o + n] = rank[t_id]
             unit_id[o:o + n] = unit
             tf[o:o + n] = tf_c
             meta[o:o + n] = meta_c
-            if ordered:
-                key = ((meta_c & 3).astype(np.int64) << 32) | unit
-                ordered = bool(key[0] >= last_key and (np.diff(key) >= 0).all())
-                last_key = int(key[-1])
             o += n
+        key = ((meta & 3).astype(np.int64) << 32) | unit_id
+        ordered = bool(R < 2 or (np.diff(key) >= 0).all())
         extra_rows = None
         if self.orphan_terms:
             extra_rows = np.bincount(rank[np.concatenate(self.orphan_terms)], minlength=max(len(terms), 1)).astype(np.int64)
-        return TokenExport(term_id, unit_id, tf, meta, terms, doc_ids, word_count, doc_flags, list(doc_urls),
-                           list(article_urls), ordered, {t: i for i, t in enumerate(terms)}, extra_rows)
+        return TokenExport(term_id, unit_id, tf, meta, terms, doc_ids, word_count, doc_flags, doc_urls,
+                           list(article_urls), ordered, {t: i for i, t in enumerate(terms)}, extra_rows, True)
 
 
 class SqlStore:
@@ -298,9 +310,10 @@ class SqlStore:
         if buf:
             yield _parse_copy_text(buf)
 
-    def export_tokens(self, alloc=None) -> TokenExport:
+    def export_tokens(self, alloc=None, collation_key=None) -> TokenExport:
         """The whole `tokens` table + the document columns the job reads, as one snapshot.
-        `alloc(n, dtype)` supplies the four row arrays (e.g. pinned host memory); default numpy."""
+        `alloc(n, dtype)` supplies the four row arrays (e.g. pinned host memory); default numpy.
+        Dense doc indices follow ascending url order under `collation_key` (default: code points)."""
         alloc = alloc or (lambda n, dt: np.empty(n, dt))
         conn = self._connect()
         try:
@@ -319,7 +332,7 @@ class SqlStore:
             asm = _Assembler(doc_ids, {u: i for i, u in enumerate(article_urls)})
             for chunk in self._token_chunks(conn, cur):
                 asm.add(*chunk)
-            ex = asm.finish(word_count, doc_flags, list(dc[1]), article_urls, alloc)
+            ex = asm.finish(word_count, doc_flags, list(dc[1]), article_urls, alloc, collation_key)
         finally:
             try:
                 conn.rollback()
