@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 timeout -s KILL 500 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o $TAG -- python3 "$REPO/bench.py" > "$OUT/bench_under_trace.json" 2> "$OUT/stats.log"
-SHORT="--steps 3 --warmup 1 --no-cpu --no-variants --query-steps 2 --k2 0"
+SHORT="--steps 3 --warmup 1 --no-cpu --no-variants --no-update --query-steps 2 --k2 0"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o $TAG -- python3 "$REPO/bench.py" $SHORT > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.log"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o $TAG -- python3 "$REPO/bench.py" $SHORT > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.log"
 timeout -s KILL 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum -d "$OUT/pmc_rd" -o $TAG -- python3 "$REPO/bench.py" $SHORT > "$OUT/pmc_rd.json" 2> "$OUT/pmc_rd.log"

@@ -63,7 +63,7 @@ def counters(path):
 fetch, write, rd, wr = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_rd"), counters("pmc_wr")
 bench = json.loads([l for l in open(os.path.join(src, "pmc_fetch.json")) if l.startswith("{")][-1])
 R = bench["config"]["rows_per_gpu"]
-SRC = ("rocprofv3 --pmc, one pass per counter group, bench.py --steps 3 --warmup 1 --no-cpu --no-variants "
+SRC = ("rocprofv3 --pmc, one pass per counter group, bench.py --steps 3 --warmup 1 --no-cpu --no-variants --no-update "
        "--query-steps 2 --k2 0; averages per launch")
 
 
