@@ -48,6 +48,19 @@ class ShardedIndex:
         e.build_local(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags,
                       unit_major=unit_major)
         e.set_unit_base(doc_base, article_base)
+        return self._reduce_and_finalize(n_terms)
+
+    def update(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
+               changed_docs=None, changed_articles=None, unit_major=False):
+        """Incremental update of this rank's shard (unit ids local to the shard, as in build): the listed units
+        are replaced by the rows given, then df and the totals are summed over the shards again and every rank
+        recomputes the same idf.  Every rank must call it (with empty arrays when its shard did not change)."""
+        self.engine.update(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags,
+                           changed_docs=changed_docs, changed_articles=changed_articles, unit_major=unit_major, local=True)
+        return self._reduce_and_finalize(n_terms)
+
+    def _reduce_and_finalize(self, n_terms):
+        e = self.engine
         if self._buf is None or self._buf.numel() != n_terms + 16:
             self._buf = torch.zeros(n_terms + 16, dtype=torch.int32, device=self.device)
             self._df = self._buf[:n_terms]

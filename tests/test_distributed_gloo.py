@@ -26,6 +26,19 @@ class OracleEngine:
         from oracle import oracle as O
         self.orc = O.OracleIndex(term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags)
 
+        self.rows = [np.array(x) for x in (term_id, unit_id, tf, meta)]
+
+    def update(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles, word_count, doc_flags, changed_docs=None,
+               changed_articles=None, unit_major=False, local=True):
+        # the stand-in has no segments: it drops the changed units' rows from its copy of the shard and rebuilds
+        o = self.rows
+        src = o[3] & 3
+        dead = ((src == 1) & np.isin(o[1], np.asarray(changed_docs if changed_docs is not None else [], np.uint32))) | \
+               ((src == 2) & np.isin(o[1], np.asarray(changed_articles if changed_articles is not None else [], np.uint32)))
+        rows = [np.concatenate([a[~dead], np.asarray(b, a.dtype)]) for a, b in zip(o, (term_id, unit_id, tf, meta))]
+        order = np.lexsort((rows[1], rows[3] & 3))
+        self.build_local(*[a[order] for a in rows], n_terms, n_docs, n_articles, word_count, doc_flags)
+
     def set_unit_base(self, web, news):
         self.base = (web, news)
 
@@ -64,7 +77,7 @@ class OracleEngine:
                 out["unit"][q, i] = u; out["score"][q, i] = -ns; out["matched"][q, i] = m; out["tie"][q, i] = t
 
 
-def _worker(rank, world, port, n_docs, n_art, V, result_path):
+def _worker(rank, world, port, n_docs, n_art, V, result_path, update=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -82,6 +95,16 @@ def _worker(rank, world, port, n_docs, n_art, V, result_path):
     qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 20, 3)
     web = sh.search(qs, 12, source=1)
     news = sh.search(qs, 12, source=2)
+    if update:
+        # the first five docs of every shard are crawled again (rows of a corpus with another seed)
+        c2 = O.gen_corpus(O.make_spec(seed=99, n_terms=V, n_docs=d1 - d0, n_articles=0, doc_begin=d0, body_min=30, body_max=90))
+        sel = c2["unit_id"] < 5
+        wc = c["word_count"].copy()
+        wc[:5] = c2["word_count"][:5]
+        t = sh.update(c2["term_id"][sel], c2["unit_id"][sel], c2["tf"][sel], c2["meta"][sel], V, d1 - d0, a1 - a0, wc,
+                      changed_docs=np.arange(5, dtype=np.uint32))
+        web = sh.search(qs, 12, source=1)
+        news = sh.search(qs, 12, source=2)
     np.savez(result_path % rank, df=sh.engine.orc.df, idf=sh.engine.orc.idf, df_global=sh._df.numpy(),
              totals=np.array([t.n_done, t.n_wc, t.sum_wc, t.n_postings]), n=sh.engine.orc.n_docs_stat,
              avgdl=sh.engine.orc.avgdl, **{f"web_{k}": v for k, v in web.items()}, **{f"news_{k}": v for k, v in news.items()})
@@ -115,6 +138,41 @@ def test_two_rank_sharded_build_and_search_equal_unsharded(tmp_path):
                 np.testing.assert_array_equal(x[f"{name}_unit"][i, :n], u)
                 np.testing.assert_array_equal(x[f"{name}_score"][i, :n], sc)
                 np.testing.assert_array_equal(x[f"{name}_matched"][i, :n], m)
+
+
+def test_two_rank_sharded_update_equals_unsharded_rebuild(tmp_path):
+    """Every shard replaces a few of its docs (sebm25_update_local's contract), df and totals are summed again:
+    statistics and both searches equal an unsharded index built from the final table."""
+    from oracle import oracle as O
+    from search_engine_amd.sharded import shard_range
+
+    n_docs, n_art, V, world = 400, 50, 2000, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = str(tmp_path / "rank%d.npz")
+    mp.start_processes(_worker, args=(world, port, n_docs, n_art, V, path, True), nprocs=world, join=True, start_method="spawn")
+    a = O.gen_corpus(O.make_spec(n_terms=V, n_docs=n_docs, n_articles=n_art, body_min=30, body_max=90))
+    b = O.gen_corpus(O.make_spec(seed=99, n_terms=V, n_docs=n_docs, n_articles=0, body_min=30, body_max=90))
+    changed = np.concatenate([np.arange(shard_range(n_docs, r, world)[0], shard_range(n_docs, r, world)[0] + 5) for r in range(world)])
+    keep = ~(((a["meta"] & 3) == 1) & np.isin(a["unit_id"], changed))
+    take = np.isin(b["unit_id"], changed)
+    rows = [np.concatenate([a[k][keep], b[k][take]]) for k in ("term_id", "unit_id", "tf", "meta")]
+    order = np.lexsort((rows[1], rows[3] & 3))
+    wc = a["word_count"].copy()
+    wc[changed] = b["word_count"][changed]
+    orc = O.OracleIndex(*[x[order] for x in rows], V, n_docs, n_art, wc)
+    qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 20, 3)
+    for i in range(world):
+        x = np.load(path % i)
+        np.testing.assert_array_equal(x["df_global"].view(np.uint32), orc.df)
+        np.testing.assert_array_equal(x["idf"], orc.idf)
+        assert int(x["n"]) == orc.n_docs_stat and float(x["avgdl"]) == orc.avgdl
+        for src, name in ((1, "web"), (2, "news")):
+            for qi, q in enumerate(qs):
+                u, sc, m = orc.search(q, 12, source=src, level="csr")
+                n = int(x[f"{name}_count"][qi])
+                assert n == len(u)
+                np.testing.assert_array_equal(x[f"{name}_unit"][qi, :n], u)
+                np.testing.assert_array_equal(x[f"{name}_score"][qi, :n], sc)
 
 
 def test_shard_ranges_cover_everything():

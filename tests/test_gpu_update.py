@@ -212,3 +212,71 @@ def test_update_of_a_larger_index(gpu_index_factory):
     assert_same_index(upd, ref, tb, rng, hot)
     upd.compact()
     assert_same_index(upd, ref, tb, rng, hot)
+
+
+def test_sharded_update_equals_unsharded_rebuild(gpu_index_factory):
+    """Two document shards on one GPU, each updated with sebm25_update_local; df and the totals summed as the
+    all-reduce would; both searches merged across the shards equal an unsharded index built from the final table."""
+    n_docs, n_art, V, G = 1600, 120, 4000, 2
+    rng = np.random.default_rng(11)
+    hot = np.arange(10, 50)
+    final_t, final_u, final_f, final_m, final_wc, final_fl = [], [], [], [], [], []
+    shards, dfs, tots, bases = [], [], [], []
+    for g in range(G):
+        d0, d1 = n_docs * g // G, n_docs * (g + 1) // G
+        a0, a1 = n_art * g // G, n_art * (g + 1) // G
+        tb = Table(O.gen_corpus(O.make_spec(n_terms=V, n_docs=d1 - d0, n_articles=a1 - a0, doc_begin=d0, article_begin=a0)))
+        ix = gpu_index_factory()
+        t, u, f, m = tb.arrays()
+        ix.build_local(t, u, f, m, V, tb.n_docs, tb.n_articles, tb.word_count, tb.flags)
+        ix.set_unit_base(d0, a0)
+        # a crawl cycle inside the shard: docs re-crawled or removed, articles replaced (id spaces fixed so that the
+        # global numbering of the other shard stays put)
+        cd = sorted(set(rng.integers(0, tb.n_docs, 40).tolist()))
+        ca = sorted(set(rng.integers(0, tb.n_articles, 8).tolist()))
+        for d in cd:
+            if rng.random() < 0.2:
+                tb.docs.pop(d, None)
+                tb.flags[d], tb.word_count[d] = 0, 0
+            else:
+                tt, tf, mm, wc = random_doc_rows(rng, V, hot)
+                tb.docs[d], tb.word_count[d] = (tt, tf, mm), wc
+        for a in ca:
+            tt = np.unique(np.concatenate([rng.integers(0, V, 12), rng.choice(hot, 2)])).astype(np.uint32)
+            tb.arts[a] = (tt, rng.integers(1, 5, len(tt)).astype(np.uint32), np.full(len(tt), NEWS | (4 << 2), np.uint8))
+        t, u, f, m = tb.arrays(cd, ca)
+        ix.update(t, u, f, m, V, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=cd, changed_articles=ca, local=True)
+        df, tt_ = ix.local_stats()
+        shards.append(ix)
+        dfs.append(df.astype(np.uint64))
+        tots.append(tt_)
+        t, u, f, m = tb.arrays()
+        web = (m & 3) == WEB
+        final_t.append(t); final_f.append(f); final_m.append(m)
+        final_u.append(np.where(web, u + d0, u + a0).astype(np.uint32))
+        final_wc.append(tb.word_count); final_fl.append(tb.flags)
+    df_global = sum(dfs).astype(np.uint32)
+    tg = se.DocTotals(sum(t.n_done for t in tots), sum(t.n_wc for t in tots), sum(t.sum_wc for t in tots), sum(t.n_postings for t in tots))
+    rows = [np.concatenate(x) for x in (final_t, final_u, final_f, final_m)]
+    order = np.lexsort((rows[1], rows[3] & 3))
+    orc = O.OracleIndex(*[x[order] for x in rows], V, n_docs, n_art, np.concatenate(final_wc), np.concatenate(final_fl))
+    np.testing.assert_array_equal(df_global, orc.df)
+    for ix in shards:
+        ix.finalize(df_global, tg)
+        st = ix.stats()
+        np.testing.assert_array_equal(st["df"], orc.df)
+        assert st["n_docs"] == orc.n_docs_stat and st["avgdl"] == orc.avgdl
+        ix.set_idf(orc.idf)
+    qs = [np.unique(np.concatenate([rng.choice(hot, 2), rng.integers(0, V, 1)])).astype(np.uint32) for _ in range(30)]
+    for source in (WEB, NEWS):
+        k = 15
+        parts = [ix.search(qs, k, source=source, want_tie=True) for ix in shards]
+        cat = {key: np.ascontiguousarray(np.stack([p[key] for p in parts])) for key in ("unit", "score", "matched", "tie", "count")}
+        merged = shards[0].merge_topk(G, len(qs), k, cat["unit"], cat["score"], cat["matched"], cat["tie"], cat["count"])
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, source=source, level="csr")
+            n = int(merged["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(merged["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(merged["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(merged["matched"][qi, :n], rm)
