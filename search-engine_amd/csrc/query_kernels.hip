@@ -459,7 +459,11 @@ struct RegTopK {
 #endif
 // 64-slot chunks of a list held in registers (and as many in flight): for the variant with the candidates in
 // registers, and for the variants with an LDS candidate buffer (smaller blocks: fewer registers)
-constexpr int STEP_BLOCK = SEBM25_STEP_BLOCK, STEP_BLOCK_MID = SEBM25_STEP_BLOCK_MID, STEP_WAVES_MID = SEBM25_STEP_WAVES_MID;
+#ifndef SEBM25_STEP_SLOTS_MID
+#define SEBM25_STEP_SLOTS_MID 512
+#endif
+constexpr int STEP_BLOCK = SEBM25_STEP_BLOCK, STEP_BLOCK_MID = SEBM25_STEP_BLOCK_MID, STEP_WAVES_MID = SEBM25_STEP_WAVES_MID,
+              STEP_SLOTS_MID = SEBM25_STEP_SLOTS_MID;
 
 #ifdef SEBM25_EXP_STATS  // experiment builds only: steps, insert passes, postings inserted, harvest rounds, offers, items
 __device__ unsigned long long g_step_stats[8];
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     // A step may bring at most LIMIT units into the table (besides up to 63 that wait from earlier steps); a
     // block-wide step that could bring more is replaced by a chunk-wide one (at most 64 slots per list).
     constexpr uint32_t STEP_SLOTS = SLOTS, STEP_LIMIT = SLOTS - 64;
-    static_assert((SLOTS & (SLOTS - 1)) == 0 && T * 64 <= (int)STEP_LIMIT, "the table never fills");
+    static_assert((SLOTS & (SLOTS - 1)) == 0 && (T - 1) * 64 <= (int)STEP_LIMIT, "the table never fills");
     __shared__ uint32_t tag[STEP_SLOTS];
 #ifdef SEBM25_WF4
     constexpr uint32_t WF = 4;
@@ -575,15 +579,14 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         uint32_t F = clast[0][B - 1];
 #pragma unroll
         for (int t = 1; t < T; ++t) F = min(F, clast[t][B - 1]);
-        // how much the block-wide step would bring
+        // how much the block-wide step would bring into the table (only the shorter lists insert)
         uint32_t n_in = 0;
-        {
+        if ((T - 1) * B * 64 > (int)STEP_LIMIT) {
             const uint32_t Fb = min(F, INF - 1u);
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
-                for (int j = 0; j < B; ++j)  // of the longest list only what passes its filter (holes count: harmless)
-                    n_in += (uint32_t)__popcll(__ballot(u[t][j] <= Fb && (t < T - 1 || w[t][j] >= w_min)));
+                for (int j = 0; j < B; ++j) n_in += (uint32_t)__popcll(__ballot(u[t][j] <= Fb));
         }
         if (n_in > STEP_LIMIT) {
             // chunk-wide step: the frontier is the smallest last unit over every list's first chunk that is not used up
@@ -630,7 +633,18 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    s = s && !found && w[t][j] >= w_min;
+                    // a unit that only this list holds has its final score already: straight to the candidates
+                    const bool alone = s && !found && w[t][j] >= w_min;
+                    if (__ballot(alone)) {
+                        const double sc = __dmul_rn(idf_last, (double)w[t][j]);
+                        const bool may = alone && sc >= tk.thr_score;
+                        if (__ballot(may)) {
+                            uint32_t tie = 0;
+                            if (may) tie = HAS_RANK ? a.url_rank[u[t][j]] : u[t][j] + a.unit_base;
+                            tk.offer(may, score_key(sc), tie, u[t][j] + a.unit_base, 1u, a.k);
+                        }
+                    }
+                    s = false;  // the longest list never inserts
                 }
                 const uint64_t sm = __ballot(s);
 #ifdef SEBM25_EXP_STATS
@@ -792,8 +806,8 @@ template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
     if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, 5, STEP_BLOCK, 512>), grid, block, 0, st, b);
-    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
-    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
+    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
     else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
 }
 template <int T>

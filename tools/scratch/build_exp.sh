@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../search-engine_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
-for f in abi build_kernels query_kernels corpus_gen; do
+for f in abi build_kernels query_kernels update_kernels corpus_gen; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function "$@" -c $f.hip -o $tmp/$f.o &
 done
 wait
