@@ -92,6 +92,7 @@ struct TopK {
         __builtin_amdgcn_wave_barrier();
     }
     static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + (HAS_TIE ? 4 : 0) + 1) + 15) / 16 * 16; }
+    static constexpr bool FILTER_MIDDLE_LISTS = false;  // measured: the lower, lazily refreshed k-th best score filters too little
     __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
 
     // one compare-exchange of the merge network: the better entry goes to slot lo
@@ -385,6 +386,8 @@ struct RegTopK {
     uint32_t thr_tie;
     double thr_score;
     static constexpr size_t bytes() { return 16; }
+    // the k-th best score is high and exact at every moment: bounds against it are worth their arithmetic
+    static constexpr bool FILTER_MIDDLE_LISTS = true;
     __device__ void init(unsigned char*) {
         key = 0;
         unit = 0xFFFFFFFFu;
@@ -449,7 +452,7 @@ struct RegTopK {
 };
 
 #ifndef SEBM25_STEP_BLOCK
-#define SEBM25_STEP_BLOCK 4
+#define SEBM25_STEP_BLOCK 2
 #endif
 #ifndef SEBM25_STEP_BLOCK_MID
 #define SEBM25_STEP_BLOCK_MID 2
@@ -459,6 +462,13 @@ struct RegTopK {
 #endif
 // 64-slot chunks of a list held in registers (and as many in flight): for the variant with the candidates in
 // registers, and for the variants with an LDS candidate buffer (smaller blocks: fewer registers)
+#ifndef SEBM25_STEP_SLOTS
+#define SEBM25_STEP_SLOTS 512
+#endif
+#ifndef SEBM25_STEP_WAVES
+#define SEBM25_STEP_WAVES 6
+#endif
+constexpr int STEP_SLOTS = SEBM25_STEP_SLOTS, STEP_WAVES = SEBM25_STEP_WAVES;
 #ifndef SEBM25_STEP_SLOTS_MID
 #define SEBM25_STEP_SLOTS_MID 512
 #endif
@@ -495,6 +505,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * WF];  // per slot and list: weight in tenths + 1
     __shared__ unsigned short used[STEP_LIMIT + 64];
     __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
+#ifdef SEBM25_EXP_PAD_LDS  // experiment builds only: more LDS per wave, i.e. fewer waves per CU
+    __shared__ uint32_t lds_pad[SEBM25_EXP_PAD_LDS / 4];
+    lds_pad[threadIdx.x] = a.k;
+    if (lds_pad[63 - threadIdx.x] == 0xFFFFFFFFu) return;
+#endif
 
     const QItem it = a.items[blockIdx.x];
     const uint32_t lane = lane_id();
@@ -545,6 +560,32 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         idf[j] = readlane_f64(my_idf, (int)p);
     }
     const double idf_last = readlane_f64(my_idf, T - 1);
+    // idf of the lists as they sit, and whether the lists between the shortest and the longest may be filtered too:
+    // bounds of the form "what the longer lists can add at most" need every idf to be positive
+    double idf_p[T], inv_idf_p[T];
+    bool all_positive = true;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        idf_p[t] = readlane_f64(my_idf, t);
+        all_positive = all_positive && idf_p[t] > 0.0 && idf_p[t] < 1e300;
+        inv_idf_p[t] = 1.0 / idf_p[t];
+    }
+    constexpr bool MIDF = T > 2 && TK::FILTER_MIDDLE_LISTS;
+    uint32_t maxw[T];       // largest weight in the list's current block
+    uint32_t w_mid[T];      // lists 1 .. T-2: smallest weight whose posting is inserted when no shorter list holds the unit
+#pragma unroll
+    for (int t = 0; t < T; ++t) w_mid[t] = 0;
+    auto block_max = [&](int t) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < B; ++j) v = max(v, w[t][j] == POST_HOLE ? 0u : w[t][j]);
+        v = max(v, lane_xor<1>(v));
+        v = max(v, lane_xor<2>(v));
+        v = max(v, lane_xor<4>(v));
+        v = max(v, lane_xor<8>(v));
+        v = max(v, lane_xor<16>(v));
+        maxw[t] = max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
+    };
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
@@ -570,9 +611,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     uint32_t st_steps = 0, st_ins = 0, st_rounds = 0, st_offers = 0, st_passes = 0;
 #endif
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
+        if (MIDF && t >= 2) block_max(t);
+    }
     __builtin_amdgcn_wave_barrier();
 
     while (true) {
@@ -604,6 +647,23 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         const uint32_t Fc = min(F, INF - 1u);
         F_prev = Fc;
 
+        // Lists between the shortest and the longest: a posting whose unit no shorter list delivered is inserted only
+        // if its own part plus the most the longer lists can add (idf x the largest weight of their current blocks,
+        // which hold every posting of this step) reaches the k-th best score.  A unit dropped here scores below that
+        // score whatever the longer lists hold for it, and whatever part of it a longer list may still offer is
+        // smaller still, so it is rejected there against the score of that moment (which only rises).
+        if (MIDF) {
+            const double thr = tk.thr_score;
+            if (all_positive && thr > 0.0) {
+                double ub = 0.0;
+#pragma unroll
+                for (int t = T - 2; t >= 1; --t) {
+                    ub += idf_p[t + 1] * (double)maxw[t + 1];
+                    const double x = (thr * (1.0 - 1e-12) - ub) * inv_idf_p[t];
+                    w_mid[t] = x < 2.0 ? 0u : (x >= 65536.0 ? 0xFFFFu : (uint32_t)x - 1u);
+                }
+            }
+        }
         bool probe = false;  // the shorter lists brought units into the table in this step
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -613,9 +673,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 const bool in = u[t][j] <= Fc;
                 if (!__ballot(in)) continue;
                 bool s = in && w[t][j] != POST_HOLE;  // a hole only leaves its chunk
-                if (t == T - 1) {
-                    // the longest list: add to units that are in the table, insert only what could rank alone
-                    bool found = false;
+#ifdef SEBM25_EXP_NOINSERT
+                if (t < T - 1) s = false;
+#endif
+                bool found = false;
+                if (t == T - 1 || (MIDF && t >= 1)) {
+                    // the filtered lists: add to units that are in the table
                     if (probe && __ballot(s)) {
                         if (s) {
                             const uint32_t un = u[t][j];
@@ -633,7 +696,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
-                    // a unit that only this list holds has its final score already: straight to the candidates
+                    if (t < T - 1) s = s && !found && w[t][j] >= w_mid[t];  // what is left goes into the table below
+                }
+                if (t == T - 1) {
+                    // a unit that only the longest list holds has its final score already: straight to the candidates
                     const bool alone = s && !found && w[t][j] >= w_min;
                     if (__ballot(alone)) {
                         const double sc = __dmul_rn(idf_last, (double)w[t][j]);
@@ -671,7 +737,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                     const uint64_t fm = __ballot(fresh);
                     if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
                     n_used += (uint32_t)__popcll(fm);
+#ifndef SEBM25_EXP_NOPROBE
                     if (t < T - 1) probe = true;
+#endif
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (!advance) u[t][j] = in ? INF : u[t][j];  // used slots leave their chunk
@@ -686,6 +754,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
 #pragma unroll
                 for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
+                if (MIDF && t >= 2) block_max(t);
             }
         }
 #ifdef SEBM25_EXP_STATS
@@ -805,7 +874,7 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, 5, STEP_BLOCK, 512>), grid, block, 0, st, b);
+    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, STEP_WAVES, STEP_BLOCK, STEP_SLOTS>), grid, block, 0, st, b);
     else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
     else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
     else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
