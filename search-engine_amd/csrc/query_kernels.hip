@@ -680,20 +680,26 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 if (t == T - 1 || (MIDF && t >= 1)) {
                     // the filtered lists: add to units that are in the table
                     if (probe && __ballot(s)) {
-                        if (s) {
-                            const uint32_t un = u[t][j];
-                            uint32_t h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
-                            while (true) {
-                                const uint32_t tg = tag[h];
-                                if (tg == un) {
-                                    found = true;
-                                    break;
+                        // nearly every lane is done after one look (its slot is empty or holds its unit)
+                        const uint32_t un = u[t][j];
+                        uint32_t h = (un ^ (un >> 9)) & (STEP_SLOTS - 1u);
+                        const uint32_t tg0 = s ? tag[h] : HASH_EMPTY;
+                        found = s && tg0 == un;
+                        bool more = s && tg0 != un && tg0 != HASH_EMPTY;
+                        if (__ballot(more)) {
+                            if (more) {
+                                while (true) {
+                                    h = (h + 1u) & (STEP_SLOTS - 1u);
+                                    const uint32_t tg = tag[h];
+                                    if (tg == un) {
+                                        found = true;
+                                        break;
+                                    }
+                                    if (tg == HASH_EMPTY) break;
                                 }
-                                if (tg == HASH_EMPTY) break;
-                                h = (h + 1u) & (STEP_SLOTS - 1u);
                             }
-                            if (found) wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                         }
+                        if (found) wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                         __builtin_amdgcn_wave_barrier();
                     }
                     if (t < T - 1) s = s && !found && w[t][j] >= w_mid[t];  // what is left goes into the table below
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                     uint32_t h = 0;
                     if (s) {
                         const uint32_t un = u[t][j];
-                        h = (un ^ (un >> 9) ^ (un >> 18)) & (STEP_SLOTS - 1u);
+                        h = (un ^ (un >> 9)) & (STEP_SLOTS - 1u);
                         while (true) {
                             const uint32_t old = atomicCAS(&tag[h], HASH_EMPTY, un);
                             if (old == HASH_EMPTY) {
