@@ -184,6 +184,11 @@ def main():
     import search_engine_amd as se
     from search_engine_amd.sharded import ShardedIndex
 
+    if os.environ.get("SEBM25_BENCH_WATCHDOG"):
+        # debugging aid: dump every thread's stack and exit if the run takes longer than this many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["SEBM25_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

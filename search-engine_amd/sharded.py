@@ -38,6 +38,10 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._buf = None   # int32[V + 16]: df, then the four totals as 16-bit limbs (one all-reduce for both)
         self._df = None
+        # gloo is a host backend: with device buffers (rehearsals and tests of the multi-rank path on one GPU) the
+        # collectives run on host copies.  With nccl (RCCL over xGMI) they run on the device buffers in place.
+        self._via_host = (dist.is_initialized() and self.world > 1 and self.device.type == "cuda"
+                          and dist.get_backend(group) == "gloo")
 
     # ---- statistics job
     def build(self, term_id, unit_id, tf, meta, n_terms, n_docs, n_articles=0, word_count=None, doc_flags=None,
@@ -71,7 +75,12 @@ class ShardedIndex:
             vals = (t.n_done, t.n_wc, t.sum_wc, t.n_postings)
             limbs = [(int(v) >> (16 * j)) & 0xFFFF for v in vals for j in range(4)]
             self._buf[n_terms:].copy_(torch.tensor(limbs, dtype=torch.int32))
-            dist.all_reduce(self._buf, group=self.group)    # SUM over shards (RCCL over xGMI with backend nccl)
+            if self._via_host:
+                tmp = self._buf.cpu()
+                dist.all_reduce(tmp, group=self.group)
+                self._buf.copy_(tmp)
+            else:
+                dist.all_reduce(self._buf, group=self.group)    # SUM over shards (RCCL over xGMI with backend nccl)
             got = self._buf[n_terms:].tolist()
             t = DocTotals(*(sum(int(got[4 * i + j]) << (16 * j) for j in range(4)) for i in range(4)))
         e.finalize(self._df, t)
@@ -117,7 +126,13 @@ class ShardedIndex:
         if self.world == 1:
             res = loc
         else:
-            dist.all_gather_into_tensor(gathered, mine, group=self.group)    # per-shard top-k lists, one collective
+            if self._via_host:
+                torch.cuda.synchronize(self.device)
+                g_host = torch.empty(gathered.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(g_host, mine.cpu(), group=self.group)
+                gathered.copy_(g_host)
+            else:
+                dist.all_gather_into_tensor(gathered, mine, group=self.group)    # per-shard top-k lists, one collective
             g = self._views(gathered, nq, k, lists=self.world)
             res = dict(unit=torch.empty_like(loc["unit"]), score=torch.empty_like(loc["score"]),
                        matched=torch.empty_like(loc["matched"]), tie=torch.empty_like(loc["tie"]),
