@@ -73,8 +73,20 @@ struct TopK {
     uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
     uint32_t thr_tie;
     double thr_score;  // thr_key as a score (-inf while fewer than k candidates are held): a cheap first test
+    // Lazy ties: the tie-break key of a candidate is rank[unit - base], a random 4-byte read.  When set, offer()
+    // takes no key (it lets every candidate in whose score reaches the k-th best) and cut() reads the keys of the
+    // waiting candidates in one go: one memory latency per 64 candidates instead of one per offer.
+    const uint32_t* lazy_rank;
+    uint32_t lazy_base;
+    static constexpr bool CAN_LAZY = HAS_TIE;
+    __device__ void set_lazy_ties(const uint32_t* rank, uint32_t base) {
+        lazy_rank = rank;
+        lazy_base = base;
+    }
 
     __device__ void init(unsigned char* lds) {
+        lazy_rank = nullptr;
+        lazy_base = 0;
         key = reinterpret_cast<uint64_t*>(lds);
         unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
         tie_ = unit + CAP;
@@ -122,7 +134,11 @@ struct TopK {
             const bool live = lane < np;
             uint64_t kk = live ? key[S + lane] : 0ull;
             uint32_t uu = live ? unit[S + lane] : 0xFFFFFFFFu;
-            uint32_t tt = HAS_TIE ? (live ? tie_[S + lane] : 0xFFFFFFFFu) : uu;
+            uint32_t tt = uu;
+            if (HAS_TIE) {
+                tt = 0xFFFFFFFFu;
+                if (live) tt = lazy_rank ? lazy_rank[uu - lazy_base] : tie_[S + lane];
+            }
             uint32_t mm = live ? mat[S + lane] : 0u;
             // one compare-exchange stage: partner = lane ^ MASK, TOP = highest bit of MASK
 #define SEBM25_EXCHANGE(MASK, TOP)                                                                       \
@@ -177,18 +193,19 @@ struct TopK {
 
     // every lane may offer one candidate; wave-uniform control flow
     __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
-        bool pass = has && better(ck, ct, thr_key, thr_tie);
+        const bool lazy = HAS_TIE && lazy_rank != nullptr;
+        bool pass = has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie));
         uint64_t pm = __ballot(pass);
         if (pm == 0) return;
         if (np + (uint32_t)__popcll(pm) > 64u) {
             cut(k);
-            pass = has && better(ck, ct, thr_key, thr_tie);
+            pass = has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie));
             pm = __ballot(pass);
         }
         if (pass) {
             const uint32_t pos = S + np + (uint32_t)__popcll(pm & lanemask_lt());
             key[pos] = ck;
-            if (HAS_TIE) tie_[pos] = ct;
+            if (HAS_TIE && !lazy) tie_[pos] = ct;
             unit[pos] = cu;
             mat[pos] = (unsigned char)cm;
         }
@@ -388,6 +405,8 @@ struct RegTopK {
     static constexpr size_t bytes() { return 16; }
     // the k-th best score is high and exact at every moment: bounds against it are worth their arithmetic
     static constexpr bool FILTER_MIDDLE_LISTS = true;
+    static constexpr bool CAN_LAZY = false;
+    __device__ void set_lazy_ties(const uint32_t*, uint32_t) {}
     __device__ void init(unsigned char*) {
         key = 0;
         unit = 0xFFFFFFFFu;
@@ -602,6 +621,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS * WF; x += 64) wfield[x] = 0;
     TK tk;
     tk.init(topk_mem);
+    constexpr bool LAZY = HAS_RANK && TK::CAN_LAZY;
+    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base);
     uint32_t n_used = 0;
     uint32_t w_min = 0;
     double thr_seen = tk.thr_score;
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         const bool may = alone && sc >= tk.thr_score;
                         if (__ballot(may)) {
                             uint32_t tie = 0;
-                            if (may) tie = HAS_RANK ? a.url_rank[u[t][j]] : u[t][j] + a.unit_base;
+                            if (may && !LAZY) tie = HAS_RANK ? a.url_rank[u[t][j]] : u[t][j] + a.unit_base;
                             tk.offer(may, score_key(sc), tie, u[t][j] + a.unit_base, 1u, a.k);
                         }
                     }
@@ -807,7 +828,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #endif
             if (__ballot(may)) {
                 uint32_t tie = 0;
-                if (may) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
+                if (may && !LAZY) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
                 tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
             }
             __builtin_amdgcn_wave_barrier();
