@@ -23,8 +23,9 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // order-preserving map double -> uint64 (larger double = larger key); every finite value > 0
+// (a zero of either sign maps to one key: the SQL comparison treats -0.0 and 0.0 as equal, so they tie)
 __device__ __forceinline__ uint64_t score_key(double s) {
-    const uint64_t b = (uint64_t)__double_as_longlong(s);
+    const uint64_t b = s == 0.0 ? 0ull : (uint64_t)__double_as_longlong(s);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 __device__ __forceinline__ double key_score(uint64_t k) {

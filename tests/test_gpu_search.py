@@ -171,3 +171,73 @@ def test_queries_with_five_to_nine_terms(built, tpq):
             np.testing.assert_array_equal(out["unit"][qi, :n], ru)
             np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
             np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+
+
+@pytest.mark.parametrize("tpq", [1, 2, 4])
+@pytest.mark.parametrize("k", [10, 100, 210])
+def test_one_two_and_four_list_queries_bit_exact(built, tpq, k):
+    """Every list count of the stepwise kernels (the longest list is filtered, with four lists two middle lists
+    are filtered against the longer ones), both sources."""
+    c, orc, ix = built
+    qs = _queries(c["n_terms"], 50, tpq, min_rank=3, seed=77 + tpq)
+    for source in (se.SRC_WEB, se.SRC_NEWS):
+        out = ix.search(qs, k, source=source)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, source=source, level="csr")
+            n = int(out["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+
+
+def test_zero_and_negative_idf_switch_the_filters_off(built):
+    """The bounds behind the list filters assume that every term adds to a score.  With idf values of zero or
+    below (df above N when docs are not 'done', or an idf table that says so) the results must still be exact."""
+    c, orc, ix = built
+    V = c["n_terms"]
+    rng = np.random.default_rng(5)
+    idf = orc.idf.copy()
+    idf[rng.random(V) < 0.3] *= -1.0
+    idf[rng.random(V) < 0.1] = 0.0
+    idf[:40] = -np.abs(idf[:40])                 # the head terms (the longest lists) among them
+    try:
+        ix.set_idf(idf)
+        orc.set_idf(idf)
+        for tpq in (1, 2, 3, 4):
+            qs = _queries(V, 40, tpq, min_rank=1, seed=900 + tpq)
+            for k in (10, 210):
+                out = ix.search(qs, k)
+                for qi, q in enumerate(qs):
+                    ru, rs, rm = orc.search(q, k, level="csr")
+                    n = int(out["count"][qi])
+                    assert n == len(ru)
+                    np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+                    np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+                    np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+    finally:
+        ix.set_idf(orc.idf)
+        orc.set_idf(orc.idf)
+
+
+def test_one_long_list_and_rare_terms(gpu_index_factory):
+    """A head term beside terms that occur a handful of times: nearly every posting of the long list is dropped
+    by the filter; k below and above the number of documents that hold a rare term."""
+    c = small_corpus(n_docs=30_000, n_terms=8000, body_min=20, body_max=60, title_len=3, desc_len=6)
+    orc = oracle_index(c)
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    ix.set_idf(orc.idf)
+    have = np.flatnonzero(orc.df >= 1)
+    rare = have[np.argsort(orc.df[have], kind="stable")[:12]].astype(np.uint32)     # the rarest terms of the corpus
+    qs = [np.array([0, r], np.uint32) for r in rare[:6]] + [np.array([1, rare[6], rare[7]], np.uint32),
+                                                            np.array([rare[8], 2, 0, rare[9]], np.uint32), np.array([0], np.uint32)]
+    for k in (1, 5, 10, 64, 65, 300):
+        out = ix.search(qs, k)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, level="csr")
+            n = int(out["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
