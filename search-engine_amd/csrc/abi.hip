@@ -2,6 +2,7 @@
 // the build / search pipelines as sequences of kernel launches, and result copies.
 #include <algorithm>
 #include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -72,7 +73,7 @@ struct sebm25_index {
     uint64_t dead_rows = 0;
     // sizes and sums over all segments (equal to V / n_docs / n_articles / P / P_web while there are no deltas)
     uint32_t V_cur = 0, n_docs_cur = 0, n_articles_cur = 0;
-    DevBuf df_sum, term_rows_sum, chg_web, chg_news, upd_ids, upd_counts;
+    DevBuf df_sum, term_rows_sum, chg_web, chg_news, chg_coarse, upd_ids, upd_counts;
 
     std::vector<uint32_t> h_row_ptr, h_news_ptr;
     bool host_ptrs_valid = false;
@@ -638,6 +639,16 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     if (ix->deltas.size() >= 64) return fail(ix, SEBM25_E_STATE, "update: 64 update segments are held; call sebm25_compact");
     const uint32_t n_docs = in->n_docs, n_arts = in->n_articles, V = in->n_terms;
     int rc;
+    const bool dbg = getenv("SEBM25_DEBUG_TIMES") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(ix->stream);
+        const double t1 = now();
+        fprintf(stderr, "[sebm25 update] %-22s %.3f ms\n", what, t1 - t0);
+        t0 = t1;
+    };
 
     // ---- the units this update replaces or removes, as bitmaps over the new id spaces
     const size_t ww = ((size_t)n_docs + 31) / 32 + 1, wn = ((size_t)n_arts + 31) / 32 + 1;
@@ -649,11 +660,20 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     uint32_t* ids_dev = ix->upd_ids.as<uint32_t>();
     if (n_cd) HIP_TRY(ix, hipMemcpyAsync(ids_dev, chg_docs, (size_t)n_cd * 4, hipMemcpyDefault, ix->stream));
     if (n_ca) HIP_TRY(ix, hipMemcpyAsync(ids_dev + n_cd, chg_arts, (size_t)n_ca * 4, hipMemcpyDefault, ix->stream));
-    launch_bitmap_set(ids_dev, n_cd, n_docs, ix->chg_web.as<uint32_t>(), ix->stream);
-    launch_bitmap_set(ids_dev + n_cd, n_ca, n_arts, ix->chg_news.as<uint32_t>(), ix->stream);
+    launch_bitmap_set(ids_dev, n_cd, n_docs, 0, ix->chg_web.as<uint32_t>(), ix->stream);
+    launch_bitmap_set(ids_dev + n_cd, n_ca, n_arts, 0, ix->chg_news.as<uint32_t>(), ix->stream);
+    // coarse copies (one bit per 2^shift units) small enough for every block of the dead-row scan to hold in LDS
+    uint32_t shift = 6;
+    while ((((size_t)n_docs >> shift) + ((size_t)n_arts >> shift)) / 8 > 16384) ++shift;
+    const uint32_t cw = (uint32_t)(((size_t)n_docs >> shift) / 32 + 1), c_words = cw + (uint32_t)(((size_t)n_arts >> shift) / 32 + 1);
+    HIP_TRY(ix, ix->chg_coarse.ensure((size_t)c_words * 4));
+    HIP_TRY(ix, hipMemsetAsync(ix->chg_coarse.p, 0, (size_t)c_words * 4, ix->stream));
+    launch_bitmap_set(ids_dev, n_cd, n_docs, shift, ix->chg_coarse.as<uint32_t>(), ix->stream);
+    launch_bitmap_set(ids_dev + n_cd, n_ca, n_arts, shift, ix->chg_coarse.as<uint32_t>() + cw, ix->stream);
     HIP_TRY(ix, hipGetLastError());
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));  // the id lists may be pageable host memory
 
+    lap("bitmaps");
     // ---- the new rows become a segment of their own (nothing that exists is touched until this has succeeded)
     sebm25_index* seg = new (std::nothrow) sebm25_index();
     if (!seg) return fail(ix, SEBM25_E_NOMEM, "update: out of host memory");
@@ -682,6 +702,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
         return fail(ix, rc, msg);
     }
 
+    lap("build of the segment");
     // ---- in every segment that exists, the rows of the changed units die
     const std::vector<sebm25_index*> segs = all_segments(ix);
     HIP_TRY(ix, ix->upd_counts.ensure(segs.size() * 4 * 8));
@@ -690,7 +711,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
         sebm25_index* g = segs[s];
         if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
         launch_tombstone(g->sorted_rows, g->R, g->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(),
-                         g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
+                         ix->chg_coarse.as<uint32_t>(), cw, c_words, shift, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
                          g->term_rows.as<uint32_t>(), ix->upd_counts.as<unsigned long long>() + 4 * s, ix->stream);
         launch_bitmap_or(g->dead_web.as<uint32_t>(), ix->chg_web.as<uint32_t>(), (uint32_t)(((size_t)g->n_docs + 31) / 32), ix->stream);
         launch_bitmap_or(g->dead_news.as<uint32_t>(), ix->chg_news.as<uint32_t>(), (uint32_t)(((size_t)g->n_articles + 31) / 32), ix->stream);
@@ -699,6 +720,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     std::vector<unsigned long long> counts(segs.size() * 4);
     HIP_TRY(ix, hipMemcpyAsync(counts.data(), ix->upd_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, ix->stream));
 
+    lap("dead rows");
     // ---- per-doc body lengths: the new segment's for changed docs
     if ((rc = grow_keep(ix, ix->doc_len, (size_t)ix->n_docs_cur * 4, std::max<size_t>(n_docs, 1) * 4))) return rc;
     launch_doc_len_merge(ix->doc_len.as<uint32_t>(), seg->doc_len.as<uint32_t>(), ix->chg_web.as<uint32_t>(), n_docs, ix->stream);
@@ -712,6 +734,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
     if ((rc = sum_term_counts(ix))) return rc;
 
+    lap("doc lengths, term sums");
     // ---- document totals from the documents columns as they are now (bm25_stats.py:9,12)
     uint64_t* scal = ix->scalars.as<uint64_t>();
     HIP_TRY(ix, hipMemsetAsync(scal + 2, 0, 24, ix->stream));
@@ -734,6 +757,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     ix->local_totals.sum_wc = h[2];
     ix->local_totals.n_postings = P_all;
     ix->finalized = false;
+    lap("document totals");
     return SEBM25_OK;
 }
 
@@ -861,7 +885,7 @@ void sebm25_destroy(sebm25_index* ix) {
     {
         DeviceGuard g(ix->device);
         (void)hipStreamSynchronize(ix->stream);
-        for (DevBuf* b : {&ix->dead_web, &ix->dead_news, &ix->df_sum, &ix->term_rows_sum, &ix->chg_web, &ix->chg_news, &ix->upd_ids,
+        for (DevBuf* b : {&ix->dead_web, &ix->dead_news, &ix->df_sum, &ix->term_rows_sum, &ix->chg_web, &ix->chg_news, &ix->chg_coarse, &ix->upd_ids,
                           &ix->upd_counts})
             b->release();
         DevBuf* all[] = {&ix->sortA, &ix->sortB, &ix->chunk_hist, &ix->group_off, &ix->bin_start, &ix->scan_tmp, &ix->row_ptr, &ix->news_ptr,

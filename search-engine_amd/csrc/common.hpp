@@ -147,10 +147,10 @@ void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_t
                          hipStream_t st);
 
 // incremental update (update_kernels.hip)
-void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm, hipStream_t st);
+void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t shift, uint32_t* bm, hipStream_t st);
 void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipStream_t st);
 void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
-                      const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
                       uint32_t* term_rows, unsigned long long* counts /* [4] */, hipStream_t st);
 void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
                          uint32_t* err, hipStream_t st);

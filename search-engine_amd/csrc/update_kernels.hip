@@ -15,9 +15,10 @@ namespace {
 __device__ __forceinline__ bool bit_of(const uint32_t* bm, uint32_t i) { return (bm[i >> 5] >> (i & 31u)) & 1u; }
 
 // bits of the listed ids (ids >= n are ignored: a removed unit beyond the id space has no rows anywhere)
-__global__ void k_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm) {
+// (with shift > 0: one bit per group of 2^shift ids, set when any id of the group is listed)
+__global__ void k_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t shift, uint32_t* bm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_ids && ids[i] < n) atomicOr(&bm[ids[i] >> 5], 1u << (ids[i] & 31u));
+    if (i < n_ids && ids[i] < n) atomicOr(&bm[(ids[i] >> shift) >> 5], 1u << ((ids[i] >> shift) & 31u));
 }
 
 __global__ void k_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words) {
@@ -25,39 +26,92 @@ __global__ void k_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words
     if (i < n_words) dst[i] |= src[i];
 }
 
-// One thread per sorted row of a segment.  A row whose unit changed in this update (and was alive here until
-// now) dies: its term loses a row; if it is the first row of its (term, source, unit) run and a web row, the
-// term loses a document (df counts web docs of any status); if its slot carried a posting, the slot becomes a
-// hole.  counts: [0] postings removed, [1] web postings removed, [2] web (term, doc) pairs removed, [3] rows.
+// One thread per sorted row of a segment, TOMB_BATCH rows per thread and round with every load of a round issued
+// before the first is used.  The test of a row is a dependent pair of reads (the row, then its unit's bit), and
+// the second is a gather that the texture path serves far below the rate rows stream in at; so each block keeps
+// coarse bitmaps in LDS (one bit per 2^shift units: "some unit of this group changed"; cw words for web docs,
+// then the words for articles) and goes to the exact bitmap in memory only for rows of a flagged group.  A row
+// whose unit changed in this update (and was alive here until now) dies: its term loses a row; if it is the first
+// row of its (term, source, unit) run and a web row, the term loses a document (df counts web docs of any
+// status); if its slot carried a posting, the slot becomes a hole.
+// counts: [0] postings removed, [1] web postings removed, [2] web (term, doc) pairs removed, [3] rows.
+constexpr int TOMB_BATCH = 8;
 __global__ __launch_bounds__(256) void k_tombstone(const uint64_t* rows, uint32_t R, RowFmt fmt, const uint32_t* chg_web,
-                                                   const uint32_t* chg_news, const uint32_t* dead_web,
+                                                   const uint32_t* chg_news, const uint32_t* coarse_g, uint32_t cw,
+                                                   uint32_t c_words, uint32_t shift, const uint32_t* dead_web,
                                                    const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
                                                    uint32_t* term_rows, unsigned long long* counts) {
+    extern __shared__ uint32_t coarse[];
+    for (uint32_t i = threadIdx.x; i < c_words; i += blockDim.x) coarse[i] = coarse_g[i];
+    __syncthreads();
     uint32_t c_post = 0, c_web = 0, c_head = 0, c_rows = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = rows[i];
-        const uint32_t src = fmt.src(r), unit = fmt.unit(r);
-        const bool dies = src ? (bit_of(chg_news, unit) && !bit_of(dead_news, unit)) : (bit_of(chg_web, unit) && !bit_of(dead_web, unit));
-        if (!dies) continue;
-        const uint32_t term = fmt.term(r);
-        atomicSub(&term_rows[term], 1u);
-        ++c_rows;
-        if (!src && (i == 0 || fmt.key(rows[i - 1]) != fmt.key(r))) {
-            atomicSub(&df[term], 1u);
-            ++c_head;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * TOMB_BATCH;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x * TOMB_BATCH + threadIdx.x; i0 < R; i0 += stride) {
+        uint64_t r[TOMB_BATCH];
+        uint32_t word[TOMB_BATCH];
+#pragma unroll
+        for (int j = 0; j < TOMB_BATCH; ++j) {
+            const uint64_t i = i0 + (uint64_t)j * blockDim.x;
+            r[j] = i < R ? rows[i] : 0ull;
         }
-        if (post_w[i] != POST_HOLE) {
-            post_w[i] = POST_HOLE;
-            ++c_post;
-            c_web += src ? 0u : 1u;
+#pragma unroll
+        for (int j = 0; j < TOMB_BATCH; ++j) {
+            const uint32_t unit = fmt.unit(r[j]), src = fmt.src(r[j]), g = unit >> shift;
+            word[j] = (coarse[(src ? cw : 0u) + (g >> 5)] >> (g & 31u)) & 1u;
+        }
+#pragma unroll
+        for (int j = 0; j < TOMB_BATCH; ++j) {
+            const uint32_t unit = fmt.unit(r[j]);
+            if (word[j]) word[j] = (fmt.src(r[j]) ? chg_news : chg_web)[unit >> 5] >> (unit & 31u);
+        }
+#pragma unroll
+        for (int j = 0; j < TOMB_BATCH; ++j) {
+            const uint64_t i = i0 + (uint64_t)j * blockDim.x;
+            const uint32_t src = fmt.src(r[j]), unit = fmt.unit(r[j]), term = fmt.term(r[j]);
+            bool dies = (word[j] & 1u) && i < R;
+            if (!__ballot(dies)) continue;
+            bool head = false;
+            if (dies) dies = !bit_of(src ? dead_news : dead_web, unit);
+            if (dies) {
+                head = !src && (i == 0 || fmt.key(rows[i - 1]) != fmt.key(r[j]));
+                if (post_w[i] != POST_HOLE) {
+                    post_w[i] = POST_HOLE;
+                    ++c_post;
+                    c_web += src ? 0u : 1u;
+                }
+                ++c_rows;
+                c_head += head ? 1u : 0u;
+            }
+            // Units that change together are neighbours in every long list, so the rows that die in one wavefront
+            // mostly share a term: one atomic per (wavefront, term) instead of one per row (atomics on one address,
+            // and on the addresses of one cache line, are served one at a time)
+            for (uint64_t m = __ballot(dies); m;) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)term, l);
+                const uint64_t same = __ballot(dies && term == t0);
+                const uint64_t heads = __ballot(dies && term == t0 && head);
+                if ((int)(threadIdx.x & 63u) == l) {
+                    atomicSub(&term_rows[t0], (uint32_t)__popcll(same));
+                    if (heads) atomicSub(&df[t0], (uint32_t)__popcll(heads));
+                }
+                m &= ~same;
+            }
         }
     }
-    if (c_rows) {
-        atomicAdd(&counts[3], (unsigned long long)c_rows);
-        if (c_post) atomicAdd(&counts[0], (unsigned long long)c_post);
-        if (c_web) atomicAdd(&counts[1], (unsigned long long)c_web);
-        if (c_head) atomicAdd(&counts[2], (unsigned long long)c_head);
+    // one set of atomics per block: every thread that saw a dying row adding to the same four words would queue
+    // hundreds of thousands of atomics on one cache line
+    __shared__ uint32_t block_sum[4];
+    if (threadIdx.x < 4) block_sum[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t c[4] = {c_post, c_web, c_head, c_rows};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c[q] += (uint32_t)__shfl_xor((int)c[q], o);
+        if ((threadIdx.x & 63u) == 0 && c[q]) atomicAdd(&block_sum[q], c[q]);
     }
+    __syncthreads();
+    if (threadIdx.x < 4 && block_sum[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)block_sum[threadIdx.x]);
 }
 
 // every row of the new segment must belong to a unit that the update lists as changed
@@ -128,20 +182,20 @@ static inline dim3 grid_for(uint64_t n, int threads, int cap = 8192) {
     return dim3((unsigned)(g < 1 ? 1 : (g > (uint64_t)cap ? (uint64_t)cap : g)));
 }
 
-void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t* bm, hipStream_t st) {
+void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t shift, uint32_t* bm, hipStream_t st) {
     if (n_ids == 0) return;
-    hipLaunchKernelGGL(k_bitmap_set, dim3((n_ids + 255) / 256), dim3(256), 0, st, ids, n_ids, n, bm);
+    hipLaunchKernelGGL(k_bitmap_set, dim3((n_ids + 255) / 256), dim3(256), 0, st, ids, n_ids, n, shift, bm);
 }
 void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipStream_t st) {
     if (n_words == 0) return;
     hipLaunchKernelGGL(k_bitmap_or, dim3((n_words + 255) / 256), dim3(256), 0, st, dst, src, n_words);
 }
 void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
-                      const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
                       uint32_t* term_rows, unsigned long long* counts, hipStream_t st) {
     if (R == 0) return;
-    hipLaunchKernelGGL(k_tombstone, grid_for(R, 256), dim3(256), 0, st, rows, (uint32_t)R, fmt, chg_web, chg_news, dead_web,
-                       dead_news, post_w, df, term_rows, counts);
+    hipLaunchKernelGGL(k_tombstone, grid_for((R + TOMB_BATCH - 1) / TOMB_BATCH, 256, 4096), dim3(256), (size_t)c_words * 4, st, rows, (uint32_t)R, fmt, chg_web, chg_news, coarse, cw, c_words, shift,
+                       dead_web, dead_news, post_w, df, term_rows, counts);
 }
 void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
                          uint32_t* err, hipStream_t st) {
