@@ -6,7 +6,7 @@
 // One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a range of
 // slots sorted by unit (a few of them holes that carry no posting).  Queries of up to four lists take the
 // stepwise kernel (k_score_step): all lists advance together to a common frontier, 64 coalesced slots per
-// list per load, integer accumulators in a small LDS hash table, and the best k in registers (k <= 64) or in
+// list per load, integer accumulators in a small LDS hash table, and the best k in registers (small k) or in
 // an LDS buffer that is merged, not re-sorted, when it fills.  Longer queries take the general kernel
 // (k_score), which walks windows of WIN consecutive unit ids with directly indexed accumulators.  Lists are
 // always added in query-term order, so a score is the same double sum whatever the work split.  No
@@ -55,17 +55,24 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     else return (uint32_t)__shfl_xor((int)v, (int)MASK);
 }
 
-// Candidate buffer of one wave (LDS) for k up to S = CAP - 64.  Slots [0, S) hold the best candidates
-// seen so far, sorted best first (dead slots hold the worst key); slots [S, S + 64) collect new
-// candidates.  When those 64 are full, cut() sorts them in registers (a 64-lane bitonic network of
-// lane-exchange steps) and merges them into the sorted part with one mirror stage and the
-// half-cleaner stages of a bitonic merge over [0, S): what falls out of the best S is dropped.
+// Candidate buffer of one wave (LDS) of CAP = S + W entries, for k up to S (S = the largest power of two that
+// leaves 32 <= W <= 64).  Slots [0, S) hold the best candidates seen so far, sorted best first (dead slots hold
+// the worst key); slots [S, S + W) collect new candidates.  When those are full, cut() sorts them in registers
+// (a 64-lane bitonic network of lane-exchange steps) and merges them into the sorted part: one mirror stage
+// against the sorted part's last 64 entries, done from the registers (what loses there is dropped, so nothing
+// goes back to the waiting slots), then the half-cleaner stages of a bitonic merge over [0, S).
 // HAS_TIE = false: the tie-break key of every candidate equals its unit (no url ranks were given),
-// so it is not stored.
-template <int CAP, bool HAS_TIE = true>
+// so it is not stored.  LAZY_ONLY: tie-break keys are always read at cut time (set_lazy_ties must be called
+// before the first offer), so the waiting slots hold none.
+constexpr uint32_t topk_sorted_size(uint32_t cap) {
+    uint32_t s = 64;
+    while (s * 2 + 32 <= cap) s *= 2;
+    return s;
+}
+template <int CAP, bool HAS_TIE = true, bool LAZY_ONLY = false>
 struct TopK {
-    static constexpr uint32_t S = CAP - 64;
-    static_assert(S >= 64 && (S & (S - 1)) == 0, "the sorted part is a power of two");
+    static constexpr uint32_t S = topk_sorted_size(CAP), W = CAP - S;
+    static_assert(W >= 32 && W <= 64 && (!LAZY_ONLY || HAS_TIE), "32 to 64 waiting slots");
     uint64_t* key;
     uint32_t* unit;
     uint32_t* tie_;          // only when HAS_TIE
@@ -91,7 +98,7 @@ struct TopK {
         key = reinterpret_cast<uint64_t*>(lds);
         unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
         tie_ = unit + CAP;
-        mat = reinterpret_cast<unsigned char*>(unit + (HAS_TIE ? 2 : 1) * CAP);
+        mat = reinterpret_cast<unsigned char*>(unit + CAP + TIES);
         ns = np = 0;
         thr_key = 0;
         thr_tie = 0xFFFFFFFFu;
@@ -104,7 +111,8 @@ struct TopK {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + (HAS_TIE ? 4 : 0) + 1) + 15) / 16 * 16; }
+    static constexpr uint32_t TIES = HAS_TIE ? (LAZY_ONLY ? S : (uint32_t)CAP) : 0u;  // tie-break keys held
+    static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + 1) + (size_t)TIES * 4 + 15) / 16 * 16; }
     static constexpr bool FILTER_MIDDLE_LISTS = false;  // measured: the lower, lazily refreshed k-th best score filters too little
     __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
 
@@ -138,7 +146,7 @@ struct TopK {
             uint32_t tt = uu;
             if (HAS_TIE) {
                 tt = 0xFFFFFFFFu;
-                if (live) tt = lazy_rank ? lazy_rank[uu - lazy_base] : tie_[S + lane];
+                if (live) tt = (LAZY_ONLY || lazy_rank) ? lazy_rank[uu - lazy_base] : tie_[S + lane];
             }
             uint32_t mm = live ? mat[S + lane] : 0u;
             // one compare-exchange stage: partner = lane ^ MASK, TOP = highest bit of MASK
@@ -166,13 +174,21 @@ struct TopK {
             SEBM25_EXCHANGE(31, 16) SEBM25_EXCHANGE(8, 8) SEBM25_EXCHANGE(4, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
             SEBM25_EXCHANGE(63, 32) SEBM25_EXCHANGE(16, 16) SEBM25_EXCHANGE(8, 8) SEBM25_EXCHANGE(4, 4) SEBM25_EXCHANGE(2, 2) SEBM25_EXCHANGE(1, 1)
 #undef SEBM25_EXCHANGE
-            key[S + lane] = kk;
-            unit[S + lane] = uu;
-            if (HAS_TIE) tie_[S + lane] = tt;
-            mat[S + lane] = (unsigned char)mm;
-            __builtin_amdgcn_wave_barrier();
-            // ---- merge: mirror stage across the boundary, then half-cleaners over the sorted part
-            order(S - 64u + lane, S + 63u - lane);
+            // ---- merge: mirror stage (sorted entry S - 64 + lane against the waiting entry of lane 63 - lane; the
+            // better one stays in the sorted part), then half-cleaners over the sorted part
+            {
+                const uint32_t rlo = lane_xor<63>((uint32_t)kk), rhi = lane_xor<63>((uint32_t)(kk >> 32));
+                const uint32_t ru = lane_xor<63>(uu), rm = lane_xor<63>(mm);
+                const uint32_t rt = HAS_TIE ? lane_xor<63>(tt) : ru;
+                const uint64_t rk = ((uint64_t)rhi << 32) | rlo;
+                const uint32_t i = S - 64u + lane;
+                if (better(rk, rt, key[i], tie(i))) {
+                    key[i] = rk;
+                    unit[i] = ru;
+                    if (HAS_TIE) tie_[i] = rt;
+                    mat[i] = (unsigned char)rm;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             for (uint32_t stride = S >> 1; stride > 0; stride >>= 1) {
 #pragma unroll 1
@@ -194,24 +210,35 @@ struct TopK {
 
     // every lane may offer one candidate; wave-uniform control flow
     __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
-        const bool lazy = HAS_TIE && lazy_rank != nullptr;
-        bool pass = has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie));
+        const bool lazy = LAZY_ONLY || (HAS_TIE && lazy_rank != nullptr);
+        auto passes = [&] { return has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie)); };
+        auto store = [&](bool p) {  // the lanes with p set append their candidates to the waiting slots
+            const uint64_t m = __ballot(p);
+            if (p) {
+                const uint32_t pos = S + np + (uint32_t)__popcll(m & lanemask_lt());
+                key[pos] = ck;
+                if (HAS_TIE && !LAZY_ONLY && !lazy) tie_[pos] = ct;
+                unit[pos] = cu;
+                mat[pos] = (unsigned char)cm;
+            }
+            np += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        };
+        bool pass = passes();
         uint64_t pm = __ballot(pass);
         if (pm == 0) return;
-        if (np + (uint32_t)__popcll(pm) > 64u) {
+        if (np + (uint32_t)__popcll(pm) > W) {
             cut(k);
-            pass = has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie));
+            pass = passes();
             pm = __ballot(pass);
         }
-        if (pass) {
-            const uint32_t pos = S + np + (uint32_t)__popcll(pm & lanemask_lt());
-            key[pos] = ck;
-            if (HAS_TIE && !lazy) tie_[pos] = ct;
-            unit[pos] = cu;
-            mat[pos] = (unsigned char)cm;
+        if (W < 64 && (uint32_t)__popcll(pm) > W) {  // more than the (now empty) waiting slots take: the lower lanes first
+            store(pass && lane_id() < 32u);
+            cut(k);
+            has = has && lane_id() >= 32u;
+            pass = passes();
         }
-        np += (uint32_t)__popcll(pm);
-        __builtin_amdgcn_wave_barrier();
+        store(pass);
     }
 
     __device__ void write_out(uint32_t k, uint32_t* o_unit, double* o_score, uint32_t* o_mat, uint32_t* o_tie,
@@ -376,7 +403,7 @@ constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
 //    running step intact.
 //  * A slot that has been used is overwritten with INF in its register, so "still to do" needs no
 //    per-list cursor: a list's part of a step is simply `unit <= F`.
-//  * For k <= 64 the best k sit in registers, one per lane, sorted; a candidate is placed with one
+//  * For small k (the launch code says how small) the best k sit in registers, one per lane, sorted; a candidate is placed with one
 //    ballot and one lane shift, and the k-th best is exact at every moment.
 //
 // Tried and dropped: dropping postings that cannot reach the current k-th best score (a per-list
@@ -523,7 +550,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     constexpr uint32_t WF = T == 3 ? 4 : T;  // fields per slot: a slot's fields are read and cleared as one word
 #endif
     __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * WF];  // per slot and list: weight in tenths + 1
-    __shared__ unsigned short used[STEP_LIMIT + 64];
+    // the list of slots in use (at most STEP_LIMIT + 63 <= STEP_SLOTS entries).  With three lists a slot's fourth
+    // field is free: entry i of the list lives there (field 3 of slot i), and the LDS saved is a wave more per CU.
+    constexpr bool USED_IN_FIELD = T == 3 && WF == 4;
+    __shared__ unsigned short used_mem[USED_IN_FIELD ? 1 : STEP_LIMIT + 64];
+    auto used = [&](uint32_t i) -> unsigned short& { return USED_IN_FIELD ? wfield[i * 4u + 3u] : used_mem[i]; };
     __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
 #ifdef SEBM25_EXP_PAD_LDS  // experiment builds only: more LDS per wave, i.e. fewer waves per CU
     __shared__ uint32_t lds_pad[SEBM25_EXP_PAD_LDS / 4];
@@ -763,7 +794,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                     }
                     const uint64_t fm = __ballot(fresh);
-                    if (fresh) used[n_used + (uint32_t)__popcll(fm & lt)] = (unsigned short)h;
+                    if (fresh) used(n_used + (uint32_t)__popcll(fm & lt)) = (unsigned short)h;
                     n_used += (uint32_t)__popcll(fm);
 #ifndef SEBM25_EXP_NOPROBE
                     if (t < T - 1) probe = true;
@@ -797,12 +828,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             double s = 0.0;
             uint32_t m = 0, unit = 0;
             if (has) {
-                const uint32_t h = used[n_used + lane];
+                const uint32_t h = used(n_used + lane);
                 unit = tag[h];
                 uint64_t f;
                 if constexpr (WF == 4) {
                     f = *reinterpret_cast<const uint64_t*>(&wfield[h * 4u]);
-                    *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = 0ull;
+                    // (a list entry in the fourth field stays: nothing writes list entries during a harvest)
+                    *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = USED_IN_FIELD ? (f & 0xFFFF000000000000ull) : 0ull;
                 } else if constexpr (WF == 2) {
                     f = *reinterpret_cast<const uint32_t*>(&wfield[h * 2u]);
                     *reinterpret_cast<uint32_t*>(&wfield[h * 2u]) = 0u;
@@ -902,10 +934,11 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    if (b.k <= 64) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, STEP_WAVES, STEP_BLOCK, STEP_SLOTS>), grid, block, 0, st, b);
-    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
-    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<320, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
+    // candidates in registers pay off while k is small (measured: faster than the LDS buffer up to k of about 48)
+    if (b.k <= 48) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, STEP_WAVES, STEP_BLOCK, STEP_SLOTS>), grid, block, 0, st, b);
+    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
 }
 template <int T>
 static void launch_step(const ScoreArgs& b, hipStream_t st) {
