@@ -1217,7 +1217,7 @@ struct PlanStore {
 };
 struct PlanInfo {
     uint32_t n_flat = 0, n_items = 0, n_tmp = 0;
-    uint32_t n_by_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t n_by_t[SCORE_FAST_T + 1] = {};
 };
 size_t plan_buckets() { return (size_t)(score_fast_max_terms() + 1) * PLAN_PER_GROUP; }
 
@@ -1248,9 +1248,9 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
         if (nf - start > MAX_QUERY_TERMS)
             return fail(ix, SEBM25_E_RANGE, "search: more than 255 distinct matching terms in one query");
         // Stepwise kernels read the lists shortest first and treat the longest one specially; the sum of a
-        // score still runs in the order the caller gave.  order = 2 bits per given position: where that term
+        // score still runs in the order the caller gave.  order = 3 bits per given position: where that term
         // now sits (identity for the general kernel, which keeps the given order).
-        uint32_t order = 0xE4u;
+        uint32_t order = 0xFAC688u;  // position j -> place j
         const size_t nt = nf - start;
         if (nt >= 2 && nt <= fast_t) {
             uint32_t given[SCORE_FAST_T], phys_of[SCORE_FAST_T];
@@ -1264,7 +1264,7 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
                 st.flat[start + p] = given[idx[p]];
                 phys_of[idx[p]] = (uint32_t)p;
             }
-            for (size_t j = 0; j < nt; ++j) order |= phys_of[j] << (2 * j);
+            for (size_t j = 0; j < nt; ++j) order |= phys_of[j] << (3 * j);
         }
         st.q_toff[q] = (uint32_t)start;
         st.q_nt[q] = (uint32_t)nt | (order << 8);
@@ -1332,15 +1332,14 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
     // counting sort on (group, length's bit count and its next four bits): order within 6 %, linear time
     auto bucket_of = [&](uint32_t i) -> uint32_t {
         const uint64_t len = st.item_len[i];
-        uint32_t bits = 0;
-        for (uint64_t l = len; l; l >>= 1) ++bits;  // 0..64
+        const uint32_t bits = len ? 64u - (uint32_t)__builtin_clzll(len) : 0u;  // 0..64
         const uint32_t frac = bits > 4 ? (uint32_t)(len >> (bits - 5)) & (PLAN_SUB - 1) : (uint32_t)len & (PLAN_SUB - 1);
         const uint32_t key = bits * PLAN_SUB + frac;  // grows with the length
         return group_of(i) * PLAN_PER_GROUP + (PLAN_PER_GROUP - 1u - key);
     };
     const size_t nb = plan_buckets();
     for (size_t b = 0; b <= nb; ++b) st.bucket[b] = 0;
-    for (uint32_t g = 0; g < 8; ++g) info.n_by_t[g] = 0;
+    for (uint32_t g = 0; g <= SCORE_FAST_T; ++g) info.n_by_t[g] = 0;
     for (uint32_t i = 0; i < n; ++i) {
         ++st.bucket[bucket_of(i) + 1];
         ++info.n_by_t[group_of(i)];

@@ -160,7 +160,7 @@ void launch_gather_live(const uint64_t* rows, uint64_t R, RowFmt from, RowFmt to
                         const uint32_t* dead_news, uint64_t* out, unsigned long long* n_out, hipStream_t st);
 
 // scoring
-constexpr uint32_t SCORE_FAST_T = 4;  // queries of up to this many lists take the stepwise kernels
+constexpr uint32_t SCORE_FAST_T = 8;  // queries of up to this many lists take the stepwise kernels
 struct QItem {
     uint32_t q;         // query index
     uint32_t term_off;  // into the flattened term list
@@ -168,7 +168,7 @@ struct QItem {
     uint32_t unit_lo, unit_hi;
     uint32_t out_slot;  // result list index (direct output row or temporary slice list)
     uint32_t direct;    // 1: writes the final result row
-    uint32_t order;     // stepwise kernels: 2 bits per term position as the caller gave it = its place in the list
+    uint32_t order;     // stepwise kernels: 3 bits per term position as the caller gave it = its place in the list
 };
 struct ScoreArgs {
     const uint32_t* row_ptr;

@@ -4,7 +4,7 @@
 //   ORDER BY score DESC, url ASC LIMIT k.
 //
 // One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a range of
-// slots sorted by unit (a few of them holes that carry no posting).  Queries of up to four lists take the
+// slots sorted by unit (a few of them holes that carry no posting).  Queries of up to eight lists take the
 // stepwise kernel (k_score_step): all lists advance together to a common frontier, 64 coalesced slots per
 // list per load, integer accumulators in a small LDS hash table, and the best k in registers (small k) or in
 // an LDS buffer that is merged, not re-sorted, when it fills.  Longer queries take the general kernel
@@ -547,9 +547,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #ifdef SEBM25_WF4
     constexpr uint32_t WF = 4;
 #else
-    constexpr uint32_t WF = T == 3 ? 4 : T;  // fields per slot: a slot's fields are read and cleared as one word
+    constexpr uint32_t WF = T > 4 ? 8 : (T == 3 ? 4 : T);  // fields per slot: a slot's fields are read and cleared as one word (two for more than four lists)
 #endif
-    __shared__ __align__(8) unsigned short wfield[STEP_SLOTS * WF];  // per slot and list: weight in tenths + 1
+    __shared__ __align__(16) unsigned short wfield[STEP_SLOTS * WF];  // per slot and list: weight in tenths + 1
     // the list of slots in use (at most STEP_LIMIT + 63 <= STEP_SLOTS entries).  With three lists a slot's fourth
     // field is free: entry i of the list lives there (field 3 of slot i), and the LDS saved is a wave more per CU.
     constexpr bool USED_IN_FIELD = T == 3 && WF == 4;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     uint32_t sh[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        const uint32_t p = sfirst((it.order >> (2 * j)) & 3u);
+        const uint32_t p = sfirst((it.order >> (3 * j)) & 7u);
         sh[j] = 16u * p;
         idf[j] = readlane_f64(my_idf, (int)p);
     }
@@ -830,8 +830,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             if (has) {
                 const uint32_t h = used(n_used + lane);
                 unit = tag[h];
-                uint64_t f;
-                if constexpr (WF == 4) {
+                uint64_t f, f_hi = 0;
+                if constexpr (WF == 8) {
+                    f = *reinterpret_cast<const uint64_t*>(&wfield[h * 8u]);
+                    f_hi = *reinterpret_cast<const uint64_t*>(&wfield[h * 8u + 4u]);
+                    *reinterpret_cast<uint64_t*>(&wfield[h * 8u]) = 0ull;
+                    *reinterpret_cast<uint64_t*>(&wfield[h * 8u + 4u]) = 0ull;
+                } else if constexpr (WF == 4) {
                     f = *reinterpret_cast<const uint64_t*>(&wfield[h * 4u]);
                     // (a list entry in the fourth field stays: nothing writes list entries during a harvest)
                     *reinterpret_cast<uint64_t*>(&wfield[h * 4u]) = USED_IN_FIELD ? (f & 0xFFFF000000000000ull) : 0ull;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 tag[h] = HASH_EMPTY;
 #pragma unroll
                 for (int j = 0; j < T; ++j) {  // the order the caller gave the terms in
-                    const uint32_t ft = (uint32_t)(f >> sh[j]) & 0xFFFFu;
+                    const uint32_t ft = (uint32_t)((WF == 8 && sh[j] >= 64u ? f_hi : f) >> (sh[j] & 63u)) & 0xFFFFu;
                     if (ft) {
                         const double v = __dmul_rn(idf[j], (double)(ft - 1u));
                         s = m ? __dadd_rn(s, v) : v;
@@ -934,11 +939,21 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    // candidates in registers pay off while k is small (measured: faster than the LDS buffer up to k of about 48)
-    if (b.k <= 48) hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, STEP_WAVES, STEP_BLOCK, STEP_SLOTS>), grid, block, 0, st, b);
-    else if (b.k <= 128) hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
-    else if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, STEP_BLOCK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, STEP_BLOCK_MID, 512>), grid, block, 0, st, b);
+    // more than four lists: only three sizes of candidate storage; with the candidates in LDS one chunk per list in
+    // registers (without the filter on the middle lists a two-chunk step would overfill the table most of the time)
+    constexpr int BLK = STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
+    if (b.k <= 48) {
+        hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS>), grid, block, 0, st, b);
+        return;
+    }
+    if constexpr (T <= 4) {
+        if (b.k <= 128) {
+            hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+            return;
+        }
+    }
+    if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, BLK_MID, 512>), grid, block, 0, st, b);
 }
 template <int T>
 static void launch_step(const ScoreArgs& b, hipStream_t st) {
@@ -962,7 +977,11 @@ void launch_score(const ScoreArgs& a, const uint32_t* n_by_t, hipStream_t st) {
         } else if (g == 0) launch_step<1>(b, st);
         else if (g == 1) launch_step<2>(b, st);
         else if (g == 2) launch_step<3>(b, st);
-        else launch_step<4>(b, st);
+        else if (g == 3) launch_step<4>(b, st);
+        else if (g == 4) launch_step<5>(b, st);
+        else if (g == 5) launch_step<6>(b, st);
+        else if (g == 6) launch_step<7>(b, st);
+        else launch_step<8>(b, st);
     }
 }
 

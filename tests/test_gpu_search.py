@@ -157,12 +157,13 @@ def test_sharded_build_and_merge_equals_unsharded(gpu_index_factory):
             np.testing.assert_array_equal(merged["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
             np.testing.assert_array_equal(merged["matched"][qi, :n], rm)
 
-@pytest.mark.parametrize("tpq", [5, 6, 8, 9])
-def test_queries_with_five_to_nine_terms(built, tpq):
-    """More lists than the fast path takes (4): the general kernel, same results."""
+@pytest.mark.parametrize("tpq", [5, 6, 7, 8, 9, 12, 40])
+def test_queries_with_five_to_forty_terms(built, tpq):
+    """Five to eight lists: the stepwise kernels with two words of accumulator fields per table slot and one chunk
+    per list in registers; more than eight: the general kernel.  Same results, every size of candidate storage."""
     c, orc, ix = built
     qs = _queries(c["n_terms"], 30, tpq, min_rank=1, seed=77 + tpq)
-    for k in (10, 100):
+    for k in (10, 100, 300):
         out = ix.search(qs, k)
         for qi, q in enumerate(qs):
             ru, rs, rm = orc.search(q, k, level="csr")
@@ -204,7 +205,7 @@ def test_zero_and_negative_idf_switch_the_filters_off(built):
     try:
         ix.set_idf(idf)
         orc.set_idf(idf)
-        for tpq in (1, 2, 3, 4):
+        for tpq in (1, 2, 3, 4, 6, 8):
             qs = _queries(V, 40, tpq, min_rank=1, seed=900 + tpq)
             for k in (10, 210):
                 out = ix.search(qs, k)
