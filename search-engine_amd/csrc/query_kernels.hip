@@ -952,8 +952,21 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
             return;
         }
     }
-    if (b.k <= 256) hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, BLK_MID, 512>), grid, block, 0, st, b);
+    if (b.k <= 256) {
+        hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+        return;
+    }
+    if constexpr (T <= 4) {  // candidate storage sized to k: the waves a CU holds fall with it (11, 7, 4 at three lists)
+        if (b.k <= 512) {
+            hipLaunchKernelGGL((k_score_step<T, TopK<576, HAS_RANK, HAS_RANK>, HAS_RANK, 2, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+            return;
+        }
+        if (b.k <= 1024) {
+            hipLaunchKernelGGL((k_score_step<T, TopK<1088, HAS_RANK, HAS_RANK>, HAS_RANK, 2, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, BLK_MID, 512>), grid, block, 0, st, b);
 }
 template <int T>
 static void launch_step(const ScoreArgs& b, hipStream_t st) {
@@ -1003,6 +1016,10 @@ void launch_merge(const MergeArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k_merge<128>, grid, block, 0, st, a);
     else if (a.k <= 256)
         hipLaunchKernelGGL(k_merge<320>, grid, block, 0, st, a);
+    else if (a.k <= 512)
+        hipLaunchKernelGGL(k_merge<576>, grid, block, 0, st, a);
+    else if (a.k <= 1024)
+        hipLaunchKernelGGL(k_merge<1088>, grid, block, 0, st, a);
     else
         hipLaunchKernelGGL(k_merge<2112>, grid, block, 0, st, a);
 }

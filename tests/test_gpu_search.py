@@ -24,7 +24,7 @@ def built(gpu_index_factory):
     return c, orc, ix
 
 
-@pytest.mark.parametrize("k", [1, 10, 64, 210, 2000])
+@pytest.mark.parametrize("k", [1, 10, 48, 49, 64, 210, 700, 2000])
 @pytest.mark.parametrize("source", [se.SRC_WEB, se.SRC_NEWS])
 def test_topk_matches_reference_formula(built, k, source):
     c, orc, ix = built
@@ -105,7 +105,7 @@ def test_sliced_long_queries_equal_unsliced(gpu_index_factory):
     gpu_build(ix, c)
     ix.set_idf(orc.idf)
     qs = np.array([[0, 1, 2], [3, 9, 700], [5, 6, 2999]], np.uint32)
-    for k in (10, 300):
+    for k in (10, 300, 700):
         out = ix.search(qs, k)
         for qi, q in enumerate(qs):
             ru, rs, rm = orc.search(q, k, level="csr")
