@@ -21,6 +21,7 @@ the rows leave through `COPY (SELECT ...) TO STDOUT` and `term_statistics` is re
 from __future__ import annotations
 
 import io
+import re
 import itertools
 import os
 from dataclasses import dataclass, field
@@ -89,24 +90,75 @@ def url_ranks(urls, key=None) -> np.ndarray:
     return rank
 
 
+class _Coded:
+    """A string column as codes into its distinct values (what a dictionary-encoding parser hands over)."""
+
+    __slots__ = ("codes", "uniq")
+
+    def __init__(self, codes, uniq):
+        self.codes = codes      # int64[n]
+        self.uniq = uniq        # list of str
+
+    def __len__(self):
+        return len(self.codes)
+
+
+_COPY_ESCAPES = {"\\\\": "\\", "\\t": "\t", "\\n": "\n", "\\r": "\r", "\\b": "\b", "\\f": "\f", "\\v": "\v"}
+_COPY_ESCAPE_RE = re.compile(r"\\[\\tnrbfv]")
+
+
+def _copy_unescape(strings: list) -> list:
+    """COPY text escapes backslash, tab, newline and a few control characters inside a value."""
+    if not any("\\" in u for u in strings):
+        return strings
+    return [_COPY_ESCAPE_RE.sub(lambda m: _COPY_ESCAPES[m.group(0)], u) for u in strings]
+
+
 def _parse_copy_text(buf: bytes):
-    """Columns of a block of `COPY ... TO STDOUT` text-format lines (tab-separated, one row per line)."""
+    """Columns of a block of `COPY ... TO STDOUT` text-format lines (tab-separated, one row per line).
+    With pyarrow: its multi-threaded reader, the two text columns dictionary-encoded in native code, so that
+    Python only ever sees the distinct strings of a block (1.7x the rate of the pandas parser on a corpus where a
+    fifth of a block's rows bring a new distinct term).  Without it: pandas."""
+    try:
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        from pyarrow import csv as pacsv
+    except ImportError:
+        return _parse_copy_text_pandas(buf)
+    names = ["d", "t", "f", "q", "a", "s"]
+    tbl = pacsv.read_csv(
+        pa.BufferReader(buf),
+        read_options=pacsv.ReadOptions(column_names=names, use_threads=True, block_size=8 << 20),
+        parse_options=pacsv.ParseOptions(delimiter="\t", quote_char=False, double_quote=False, escape_char=False,
+                                         newlines_in_values=False),
+        convert_options=pacsv.ConvertOptions(column_types={"d": pa.int64(), "t": pa.string(), "f": pa.int64(), "q": pa.int64(),
+                                                           "a": pa.string(), "s": pa.int64()},
+                                             null_values=[], strings_can_be_null=False, quoted_strings_can_be_null=False))
+
+    def coded(col):
+        enc = pc.dictionary_encode(tbl[col].combine_chunks())
+        return _Coded(enc.indices.to_numpy(zero_copy_only=False).astype(np.int64), _copy_unescape(enc.dictionary.to_pylist()))
+
+    num = lambda col: tbl[col].to_numpy()  # noqa: E731
+    return (num("d"), coded("t"), num("f"), num("q"), coded("a"), num("s"))
+
+
+def _parse_copy_text_pandas(buf: bytes):
     import pandas as pd
 
     df = pd.read_csv(io.BytesIO(buf), sep="\t", header=None, quoting=3, na_filter=False, engine="c",
                      dtype={0: np.int64, 1: str, 2: np.int64, 3: np.int64, 4: str, 5: np.int64}, encoding="utf-8")
-    urls = df[4].to_numpy(dtype=object)
-    if len(urls) and any("\\" in u for u in set(urls.tolist())):    # COPY escapes backslash, tab, newline
-        esc = {"\\\\": "\\", "\\t": "\t", "\\n": "\n", "\\r": "\r"}
-        import re
-
-        pat = re.compile(r"\\[\\tnr]")
-        urls = np.array([pat.sub(lambda m: esc[m.group(0)], u) for u in urls.tolist()], dtype=object)
-    return (df[0].to_numpy(), df[1].to_numpy(dtype=object), df[2].to_numpy(), df[3].to_numpy(), urls, df[5].to_numpy())
+    cols = []
+    for c in (1, 4):
+        codes, uniq = pd.factorize(df[c].to_numpy(dtype=object))
+        cols.append(_Coded(codes.astype(np.int64), _copy_unescape(uniq.tolist())))
+    return (df[0].to_numpy(), cols[0], df[2].to_numpy(), df[3].to_numpy(), cols[1], df[5].to_numpy())
 
 
 def _factorize(strings):
     """-> (codes int64[n], distinct strings as a list): hash-based, one pass, no sort."""
+    if isinstance(strings, _Coded):
+        return strings.codes, strings.uniq
     import pandas as pd
 
     codes, uniq = pd.factorize(np.asarray(strings, dtype=object))
@@ -160,7 +212,10 @@ class _Assembler:
                 self.orphan_terms.append(term_id[web][null_doc])
         # ---- news rows: article index by url
         if news.any():
-            ia, ua = _factorize(np.asarray(art, dtype=object)[news])
+            if isinstance(art, _Coded):
+                ia, ua = art.codes[news], art.uniq
+            else:
+                ia, ua = _factorize(np.asarray(art, dtype=object)[news])
             ai = self.art_index
             amap = np.fromiter((ai.get(x, -1) for x in ua), np.int64, len(ua))
             a_unit = amap[ia]

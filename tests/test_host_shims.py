@@ -470,3 +470,24 @@ def test_engine_update_on_gpu(tmp_path):
     engine = check_engine_update(tmp_path, None)
     assert engine.index.info().n_segments in (1, 2)      # a tiny index crosses the dead-row threshold and is compacted at once
     engine.index.close()
+
+
+def test_copy_text_parsers_agree_on_escapes_and_empty_fields():
+    """COPY text escapes backslash, tab and newline inside a value; both parsers (pyarrow when importable, pandas)
+    must hand the assembler the same columns."""
+    from search_engine_amd import store as S
+
+    urls = ["https://a.example/x", "https://a.example/tab\there", "https://a.example/back\\slash", "", "https://a.example/nl\nx"]
+    terms = ["plain", "back\\slash", "tab\tbed", "plain", "ünï"]
+
+    def esc(v):
+        return v.replace("\\", "\\\\").replace("\t", "\\t").replace("\n", "\\n")
+
+    lines = "".join(f"{i - 1}\t{esc(t)}\t{i % 3 + 1}\t{i + 1}\t{esc(u)}\t{1 + (i % 2)}\n" for i, (t, u) in enumerate(zip(terms, urls)))
+    got = [S._parse_copy_text(lines.encode()), S._parse_copy_text_pandas(lines.encode())]
+    for cols in got:
+        d, t, f, q, a, s = cols
+        assert d.tolist() == [-1, 0, 1, 2, 3] and f.tolist() == [1, 2, 3, 1, 2] and q.tolist() == [1, 2, 3, 4, 5]
+        assert s.tolist() == [1, 2, 1, 2, 1]
+        assert [t.uniq[c] for c in t.codes.tolist()] == terms
+        assert [a.uniq[c] for c in a.codes.tolist()] == urls
