@@ -941,7 +941,9 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
     // more than four lists: only three sizes of candidate storage; with the candidates in LDS one chunk per list in
     // registers (without the filter on the middle lists a two-chunk step would overfill the table most of the time)
-    constexpr int BLK = STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
+    // up to three lists with the candidates in registers: blocks of three chunks (the longest list, which sets most
+    // frontiers, then delivers 192 slots per step; with four lists a three-chunk step could overfill the table)
+    constexpr int BLK = T <= 3 ? STEP_BLOCK + 1 : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
     if (b.k <= 48) {
         hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS>), grid, block, 0, st, b);
         return;
