@@ -536,7 +536,7 @@ __device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__buil
 //    only when that alone reaches the k-th best score held so far (w_min = the smallest such weight, 0 while
 //    fewer than k candidates are held).  Postings of units that a shorter list delivered in this step are found
 //    by probing the table and add their field to the entry.
-template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD, int B, int SLOTS>
+template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD, int B, int SLOTS, int BL = B>
 __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) {
     static_assert(T >= 1 && T <= FAST_T, "one 16-bit accumulator field per list");
     // A step may bring at most LIMIT units into the table (besides up to 63 that wait from earlier steps); a
@@ -581,20 +581,26 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     // weights of slot pos + 64 j + lane) and the next one.  A slot outside [cursor, end) and a slot already used
     // read as INF.  clast[t][j]: the unit in the last lane of chunk j as it was loaded.
     uint32_t pos[T], end[T];
-    uint32_t u[T][B], w[T][B], nu[T][B], nw[T][B], clast[T][B];
+    // chunks per block: BL for the longest list (it sets most frontiers: the longer its block, the fewer steps), B for
+    // the others (what they bring in one step must fit the table)
+    constexpr int BM = B > BL ? B : BL;
+    auto nb = [](int t) constexpr { return t == T - 1 ? BL : B; };
+    uint32_t u[T][BM], w[T][BM], nu[T][BM], nw[T][BM], clast[T][BM];
     double idf[T];
-    auto load_block = [&](int t, uint32_t p, uint32_t lo, uint32_t (&uu)[B], uint32_t (&ww)[B]) {
-        if (p >= lo && p + 64u * B <= end[t]) {  // inside the list: no masks
+    auto load_block = [&](int t, uint32_t p, uint32_t lo, uint32_t (&uu)[BM], uint32_t (&ww)[BM]) {
+        if (p >= lo && p + 64u * nb(t) <= end[t]) {  // inside the list: no masks
             const uint32_t* pu = a.post_unit + p;
             const uint32_t* pw = a.post_w + p;
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
+            for (int j = 0; j < BM; ++j) {
+                if (j >= nb(t)) break;
                 uu[j] = pu[64u * j + lane];
                 ww[j] = pw[64u * j + lane];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
+            for (int j = 0; j < BM; ++j) {
+                if (j >= nb(t)) break;
                 const uint32_t i = p + 64u * (uint32_t)j + lane;
                 const bool ok = i >= lo && i < end[t];
                 uu[j] = ok ? a.post_unit[i] : INF;
@@ -629,7 +635,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     auto block_max = [&](int t) {
         uint32_t v = 0;
 #pragma unroll
-        for (int j = 0; j < B; ++j) v = max(v, w[t][j] == POST_HOLE ? 0u : w[t][j]);
+        for (int j = 0; j < BM; ++j)
+            if (j < nb(t)) v = max(v, w[t][j] == POST_HOLE ? 0u : w[t][j]);
         v = max(v, lane_xor<1>(v));
         v = max(v, lane_xor<2>(v));
         v = max(v, lane_xor<4>(v));
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             end[t] = 0;
         }
         load_block(t, pos[t], cur, u[t], w[t]);
-        load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
+        load_block(t, pos[t] + 64u * nb(t), 0u, nu[t], nw[t]);
     }
     for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS; x += 64) tag[x] = HASH_EMPTY;
     for (uint32_t x = lane; x < (uint32_t)STEP_SLOTS * WF; x += 64) wfield[x] = 0;
@@ -666,15 +673,16 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #pragma unroll
     for (int t = 0; t < T; ++t) {
 #pragma unroll
-        for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
+        for (int j = 0; j < BM; ++j)
+            if (j < nb(t)) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
         if (MIDF && t >= 2) block_max(t);
     }
     __builtin_amdgcn_wave_barrier();
 
     while (true) {
-        uint32_t F = clast[0][B - 1];
+        uint32_t F = clast[0][nb(0) - 1];
 #pragma unroll
-        for (int t = 1; t < T; ++t) F = min(F, clast[t][B - 1]);
+        for (int t = 1; t < T; ++t) F = min(F, clast[t][nb(t) - 1]);
         // how much the block-wide step would bring into the table (only the shorter lists insert)
         uint32_t n_in = 0;
         if ((T - 1) * B * 64 > (int)STEP_LIMIT) {
@@ -682,16 +690,17 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #pragma unroll
             for (int t = 0; t + 1 < T; ++t)
 #pragma unroll
-                for (int j = 0; j < B; ++j) n_in += (uint32_t)__popcll(__ballot(u[t][j] <= Fb));
+                for (int j = 0; j < B; ++j) n_in += (uint32_t)__popcll(__ballot(u[t][j] <= Fb));  // (t < T - 1: B chunks)
         }
         if (n_in > STEP_LIMIT) {
             // chunk-wide step: the frontier is the smallest last unit over every list's first chunk that is not used up
             F = INF;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                uint32_t c = clast[t][B - 1];
+                uint32_t c = clast[t][nb(t) - 1];
 #pragma unroll
-                for (int j = B - 2; j >= 0; --j) c = (first_step || clast[t][j] > F_prev) ? clast[t][j] : c;
+                for (int j = BM - 2; j >= 0; --j)
+                    if (j <= nb(t) - 2) c = (first_step || clast[t][j] > F_prev) ? clast[t][j] : c;
                 F = min(F, c);
             }
         }
@@ -720,9 +729,10 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         bool probe = false;  // the shorter lists brought units into the table in this step
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const bool advance = clast[t][B - 1] <= Fc;  // the block is used up by this step
+            const bool advance = clast[t][nb(t) - 1] <= Fc;  // the block is used up by this step
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
+            for (int j = 0; j < BM; ++j) {
+                if (j >= nb(t)) break;
                 const bool in = u[t][j] <= Fc;
                 if (!__ballot(in)) continue;
                 bool s = in && w[t][j] != POST_HOLE;  // a hole only leaves its chunk
@@ -805,14 +815,16 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             }
             if (advance) {  // the block in flight becomes the current one, the one behind it is requested
 #pragma unroll
-                for (int j = 0; j < B; ++j) {
+                for (int j = 0; j < BM; ++j) {
+                    if (j >= nb(t)) break;
                     u[t][j] = nu[t][j];
                     w[t][j] = nw[t][j];
                 }
-                pos[t] += 64u * B;
-                load_block(t, pos[t] + 64u * B, 0u, nu[t], nw[t]);
+                pos[t] += 64u * nb(t);
+                load_block(t, pos[t] + 64u * nb(t), 0u, nu[t], nw[t]);
 #pragma unroll
-                for (int j = 0; j < B; ++j) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
+                for (int j = 0; j < BM; ++j)
+                    if (j < nb(t)) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
                 if (MIDF && t >= 2) block_max(t);
             }
         }
@@ -941,11 +953,11 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
     // more than four lists: only three sizes of candidate storage; with the candidates in LDS one chunk per list in
     // registers (without the filter on the middle lists a two-chunk step would overfill the table most of the time)
-    // up to three lists with the candidates in registers: blocks of three chunks (the longest list, which sets most
-    // frontiers, then delivers 192 slots per step; with four lists a three-chunk step could overfill the table)
-    constexpr int BLK = T <= 3 ? STEP_BLOCK + 1 : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
+    // candidates in registers: the longest list, which sets most frontiers, holds blocks of four chunks (256 slots per
+    // step), the shorter lists blocks of two (what they bring in a step must fit the table)
+    constexpr int BLK = STEP_BLOCK, BLK_L = T <= 4 ? 2 * STEP_BLOCK : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
     if (b.k <= 48) {
-        hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS, BLK_L>), grid, block, 0, st, b);
         return;
     }
     if constexpr (T <= 4) {
