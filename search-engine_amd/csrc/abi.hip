@@ -1231,8 +1231,19 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
     const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
     size_t nf = 0;
     uint64_t total_len = 0;
+    // the list bounds of a term are two reads at random places of two arrays of V entries: ask for those of the
+    // terms a few queries ahead while this query is planned
+    const uint64_t n_q_terms = q_offsets[n_queries];
+    constexpr uint64_t AHEAD = 24;
     for (uint32_t q = 0; q < n_queries; ++q) {
         if (q_offsets[q + 1] < q_offsets[q]) return fail(ix, SEBM25_E_INVALID, "search: q_offsets must be non-decreasing");
+        for (uint64_t j = q_offsets[q] + AHEAD, e = std::min(q_offsets[q + 1] + AHEAD, n_q_terms); j < e; ++j) {
+            const uint32_t t = q_terms[j];
+            if (t < ix->V) {
+                __builtin_prefetch(&rp[t]);
+                __builtin_prefetch(&np[t]);
+            }
+        }
         const size_t start = nf;
         uint64_t len = 0;
         for (uint64_t j = q_offsets[q]; j < q_offsets[q + 1]; ++j) {
