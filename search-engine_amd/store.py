@@ -28,6 +28,14 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+try:  # optional: the fast COPY text reader and the native term dictionary (imported here, on the importing thread:
+    # a first import of pyarrow from a worker thread of a process that holds torch has crashed the interpreter)
+    import pyarrow as _pa
+    import pyarrow.compute as _pc
+    from pyarrow import csv as _pacsv
+except ImportError:  # pragma: no cover - pyarrow is present in the build container
+    _pa = _pc = _pacsv = None
+
 TOKEN_COLUMNS = ("COALESCE(doc_id, -1), term, field, frequency, COALESCE(article_url, ''), COALESCE(source_type, 1)")
 
 # what a failed text decode of row metadata looks like: the reference falls back to a statement without
@@ -91,13 +99,22 @@ def url_ranks(urls, key=None) -> np.ndarray:
 
 
 class _Coded:
-    """A string column as codes into its distinct values (what a dictionary-encoding parser hands over)."""
+    """A string column as codes into its distinct values (what a dictionary-encoding parser hands over).  The
+    distinct values are a Python list or, from the pyarrow parser, an arrow string array (`arrow`), turned into a
+    list only when somebody asks for it."""
 
-    __slots__ = ("codes", "uniq")
+    __slots__ = ("codes", "_uniq", "arrow")
 
-    def __init__(self, codes, uniq):
+    def __init__(self, codes, uniq=None, arrow=None):
         self.codes = codes      # int64[n]
-        self.uniq = uniq        # list of str
+        self._uniq = uniq       # list of str, or None while only `arrow` holds the values
+        self.arrow = arrow
+
+    @property
+    def uniq(self):
+        if self._uniq is None:
+            self._uniq = self.arrow.to_pylist()
+        return self._uniq
 
     def __len__(self):
         return len(self.codes)
@@ -117,14 +134,11 @@ def _copy_unescape(strings: list) -> list:
 def _parse_copy_text(buf: bytes):
     """Columns of a block of `COPY ... TO STDOUT` text-format lines (tab-separated, one row per line).
     With pyarrow: its multi-threaded reader, the two text columns dictionary-encoded in native code, so that
-    Python only ever sees the distinct strings of a block (1.7x the rate of the pandas parser on a corpus where a
-    fifth of a block's rows bring a new distinct term).  Without it: pandas."""
-    try:
-        import pyarrow as pa
-        import pyarrow.compute as pc
-        from pyarrow import csv as pacsv
-    except ImportError:
+    Python sees none of a block's strings (the assembler merges the block's dictionary into its own in arrow arrays):
+    2.3x the rate of the pandas parser.  Without it: pandas."""
+    if _pa is None:
         return _parse_copy_text_pandas(buf)
+    pa, pc, pacsv = _pa, _pc, _pacsv
     names = ["d", "t", "f", "q", "a", "s"]
     tbl = pacsv.read_csv(
         pa.BufferReader(buf),
@@ -137,7 +151,11 @@ def _parse_copy_text(buf: bytes):
 
     def coded(col):
         enc = pc.dictionary_encode(tbl[col].combine_chunks())
-        return _Coded(enc.indices.to_numpy(zero_copy_only=False).astype(np.int64), _copy_unescape(enc.dictionary.to_pylist()))
+        codes = enc.indices.to_numpy(zero_copy_only=False).astype(np.int64)
+        values = enc.dictionary
+        if len(values) and pc.any(pc.match_substring(values, "\\")).as_py():   # escapes are rare: only then through Python
+            return _Coded(codes, _copy_unescape(values.to_pylist()))
+        return _Coded(codes, arrow=values)
 
     num = lambda col: tbl[col].to_numpy()  # noqa: E731
     return (num("d"), coded("t"), num("f"), num("q"), coded("a"), num("s"))
@@ -171,7 +189,9 @@ class _Assembler:
     def __init__(self, doc_ids: np.ndarray, art_index: dict):
         self.doc_ids = doc_ids
         self.art_index = art_index
-        self.term_index: dict = {}
+        self.term_index: dict = {}       # term -> provisional id (order of first appearance), when pyarrow is absent
+        # with pyarrow: the distinct terms so far as one arrow string array, same ids
+        self.term_arrow = _pa.array([], _pa.string()) if _pa is not None else None
         self.parts: list = []            # (term_id, unit, tf, meta)
         self.unknown_docs: list = []     # int64 arrays of doc ids that `documents` does not hold
         self.orphan_terms: list = []     # term ids of rows without a unit
@@ -185,9 +205,12 @@ class _Assembler:
         doc_id = np.asarray(doc_id, np.int64)
         st = np.asarray(st, np.int64)
         # ---- terms: unique strings of the chunk, then one dictionary access per distinct term
-        inv, uniq = _factorize(term)
-        ti = self.term_index
-        ids = np.fromiter((ti.setdefault(t, len(ti)) for t in uniq), np.int64, len(uniq))
+        if self.term_arrow is not None:
+            inv, ids = self._term_ids_arrow(term)
+        else:
+            inv, uniq = _factorize(term)
+            ti = self.term_index
+            ids = np.fromiter((ti.setdefault(t, len(ti)) for t in uniq), np.int64, len(uniq))
         term_id = ids[inv]
         news = st == 2
         unit = np.zeros(n, np.int64)
@@ -232,6 +255,26 @@ class _Assembler:
             term_id, unit, tf, meta = term_id[keep], unit[keep], tf[keep], meta[keep]
         self.parts.append((term_id, unit, tf.astype(np.uint32), meta))
 
+    def _term_ids_arrow(self, term):
+        """-> (codes of the chunk's rows, provisional id per code): the chunk's distinct terms are looked up in, and
+        the new ones appended to, the arrow array of all distinct terms; no Python string is made."""
+        pa, pc = _pa, _pc
+        if isinstance(term, _Coded):
+            inv = term.codes
+            values = term.arrow if term.arrow is not None else pa.array(term.uniq, pa.string())
+        else:
+            inv, uniq = _factorize(term)
+            values = pa.array(uniq, pa.string())
+        known = self.term_arrow
+        where = pc.index_in(values, value_set=known) if len(known) else pa.nulls(len(values), pa.int32())
+        is_new = pc.is_null(where).to_numpy(zero_copy_only=False)
+        ids = where.fill_null(0).to_numpy(zero_copy_only=False).astype(np.int64)
+        n_new = int(is_new.sum())
+        if n_new:
+            ids[is_new] = len(known) + np.arange(n_new, dtype=np.int64)
+            self.term_arrow = pa.concat_arrays([known, values.filter(pa.array(is_new))])
+        return inv, ids
+
     def finish(self, docs_word_count, docs_flags, doc_urls, article_urls, alloc, collation_key=None) -> TokenExport:
         R = sum(len(p[0]) for p in self.parts)
         term_id = alloc(R, np.uint32)
@@ -239,8 +282,12 @@ class _Assembler:
         tf = alloc(R, np.uint32)
         meta = alloc(R, np.uint8)
         # final term ids: rank of the term among the distinct terms (deterministic whatever the row order)
-        terms_seen = list(self.term_index)
-        order = np.argsort(np.array(terms_seen, dtype="U"), kind="stable") if terms_seen else np.zeros(0, np.int64)
+        if self.term_arrow is not None:
+            terms_seen = self.term_arrow.to_pylist()
+            order = _pc.sort_indices(self.term_arrow).to_numpy(zero_copy_only=False).astype(np.int64)   # UTF-8 byte order = code-point order
+        else:
+            terms_seen = list(self.term_index)
+            order = np.argsort(np.array(terms_seen, dtype="U"), kind="stable") if terms_seen else np.zeros(0, np.int64)
         rank = np.empty(len(terms_seen), np.int64)
         rank[order] = np.arange(len(terms_seen))
         terms = [terms_seen[i] for i in order.tolist()]

@@ -69,6 +69,9 @@ from search_engine_amd import store as S  # noqa: E402
 frame = pd.DataFrame({0: ex.doc_ids[ex.unit_id], 1: np.array(ex.terms, dtype=object)[ex.term_id], 2: ex.meta >> 2, 3: ex.tf,
                       4: "", 5: ex.meta & 3})
 blocks = [frame.iloc[i:i + (1 << 20)].to_csv(sep="\t", header=False, index=False).encode() for i in range(0, len(frame), 1 << 20)]
+del frame, tid, uid, tf, meta, docs, terms          # the legs above leave tens of millions of objects behind: the
+import gc                                            # collector would walk them again and again during this leg
+gc.collect()
 t0 = time.perf_counter()
 asm = S._Assembler(ex.doc_ids, {})
 for b in blocks:
