@@ -395,22 +395,33 @@ class SqlStore:
                    a[:, 5].astype(np.int64))
 
     def _copy_chunks(self, cur, sql, block_bytes: int = 64 << 20):
+        """Blocks of whole COPY lines, parsed by two worker threads (the native parser releases the interpreter
+        lock) while this thread reads the socket and the caller assembles the block before; results in order."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
         pend = []
         size = 0
-        with cur.copy(f"COPY ({sql}) TO STDOUT") as cp:
-            for data in cp:
-                b = bytes(data)
-                pend.append(b)
-                size += len(b)
-                if size >= block_bytes:
-                    buf = b"".join(pend)
-                    cut = buf.rfind(b"\n") + 1
-                    if cut:
-                        yield _parse_copy_text(buf[:cut])
-                    pend, size = [buf[cut:]], len(buf) - cut
-        buf = b"".join(pend)
-        if buf:
-            yield _parse_copy_text(buf)
+        jobs: deque = deque()
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            with cur.copy(f"COPY ({sql}) TO STDOUT") as cp:
+                for data in cp:
+                    b = bytes(data)
+                    pend.append(b)
+                    size += len(b)
+                    if size >= block_bytes:
+                        buf = b"".join(pend)
+                        cut = buf.rfind(b"\n") + 1
+                        if cut:
+                            jobs.append(pool.submit(_parse_copy_text, buf[:cut]))
+                        pend, size = [buf[cut:]], len(buf) - cut
+                        while len(jobs) > 2:
+                            yield jobs.popleft().result()
+            buf = b"".join(pend)
+            if buf:
+                jobs.append(pool.submit(_parse_copy_text, buf))
+            while jobs:
+                yield jobs.popleft().result()
 
     def export_tokens(self, alloc=None, collation_key=None) -> TokenExport:
         """The whole `tokens` table + the document columns the job reads, as one snapshot.

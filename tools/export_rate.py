@@ -72,12 +72,25 @@ blocks = [frame.iloc[i:i + (1 << 20)].to_csv(sep="\t", header=False, index=False
 del frame, tid, uid, tf, meta, docs, terms          # the legs above leave tens of millions of objects behind: the
 import gc                                            # collector would walk them again and again during this leg
 gc.collect()
+class _Stream:      # what psycopg's cursor.copy() hands over: an iterable of byte pieces
+    def __enter__(self):
+        return (b[i:i + (1 << 20)] for b in blocks for i in range(0, len(b), 1 << 20))
+
+    def __exit__(self, *a):
+        return False
+
+
+class _Cursor:
+    def copy(self, sql):
+        return _Stream()
+
+
 t0 = time.perf_counter()
 asm = S._Assembler(ex.doc_ids, {})
-for b in blocks:
-    asm.add(*S._parse_copy_text(b))
+for cols in SqlStore(None, "%s")._copy_chunks(_Cursor(), "SELECT ..."):
+    asm.add(*cols)
 ex2 = asm.finish(ex.word_count, ex.doc_flags, ex.doc_urls, [], lambda n, dt: np.empty(n, dt))
 dt3 = time.perf_counter() - t0
 assert np.array_equal(ex2.term_id, ex.term_id) and np.array_equal(ex2.unit_id, ex.unit_id) and np.array_equal(ex2.tf, ex.tf)
 print(f"COPY text -> arrays: {len(ex2.term_id)} rows ({sum(map(len, blocks)) / 1e6:.0f} MB) in {dt3:.2f} s = {len(ex2.term_id) / dt3:.3e} rows/s "
-      "(one core; excludes the server and the socket)", flush=True)
+      "(this thread plus two parser threads; excludes the server and the socket)", flush=True)
