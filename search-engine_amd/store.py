@@ -131,6 +131,16 @@ def _copy_unescape(strings: list) -> list:
     return [_COPY_ESCAPE_RE.sub(lambda m: _COPY_ESCAPES[m.group(0)], u) for u in strings]
 
 
+def _copy_in_text(terms, df, idf, avgdl, rows_per_block: int = 1 << 16):
+    """COPY text-format lines for `term_statistics`, a block of rows at a time: floats as their shortest
+    round-trip decimal (the server parses them back to the same float8), text escaped as COPY expects."""
+    avg = repr(float(avgdl))
+    esc = str.maketrans({"\\": "\\\\", "\t": "\\t", "\n": "\\n", "\r": "\\r"})
+    for i in range(0, len(terms), rows_per_block):
+        j = i + rows_per_block
+        yield "".join(f"{t.translate(esc)}\t{d}\t{x!r}\t{avg}\n" for t, d, x in zip(terms[i:j], df[i:j], idf[i:j])).encode()
+
+
 def _parse_copy_text(buf: bytes):
     """Columns of a block of `COPY ... TO STDOUT` text-format lines (tab-separated, one row per line).
     With pyarrow: its multi-threaded reader, the two text columns dictionary-encoded in native code, so that
@@ -510,8 +520,8 @@ class SqlStore:
                 cur.execute("DELETE FROM term_statistics")
             if self.postgres and hasattr(cur, "copy"):
                 with cur.copy("COPY term_statistics (term, doc_frequency, idf, avg_doc_len) FROM STDIN") as cp:
-                    for row in zip(t_sel, df_sel, idf_sel, itertools.repeat(avgdl)):
-                        cp.write_row(row)
+                    for block in _copy_in_text(t_sel, df_sel, idf_sel, avgdl):
+                        cp.write(block)
             else:
                 p = self._p
                 cur.executemany(f"INSERT INTO term_statistics(term, doc_frequency, idf, avg_doc_len) VALUES ({p},{p},{p},{p})",

@@ -491,3 +491,48 @@ def test_copy_text_parsers_agree_on_escapes_and_empty_fields():
         assert s.tolist() == [1, 2, 1, 2, 1]
         assert [t.uniq[c] for c in t.codes.tolist()] == terms
         assert [a.uniq[c] for c in a.codes.tolist()] == urls
+
+
+def test_term_statistics_write_back_as_copy_text():
+    """PostgreSQL leg of the write-back without a server: TRUNCATE + COPY ... FROM STDIN in one transaction, a
+    statistics row for every term that has token rows (also those whose rows have no unit), floats that parse back
+    to the same bits, text escaped the way COPY reads it."""
+    log = []
+
+    class Copy:
+        def __enter__(self):
+            return self
+        def __exit__(self, *a):
+            return False
+        def write(self, data):
+            log.append(("data", bytes(data)))
+
+    class Cur:
+        def execute(self, sql, params=()):
+            log.append(("sql", sql))
+        def copy(self, sql):
+            log.append(("copy", sql))
+            return Copy()
+
+    class Conn:
+        def cursor(self):
+            return Cur()
+        def commit(self):
+            log.append(("commit",))
+        def rollback(self):
+            log.append(("rollback",))
+        def close(self):
+            pass
+
+    terms = ["alpha", "tab\there", "back\\slash", "norows", "orphan"]
+    df = np.array([3, 1, 2, 0, 0]); idf = np.array([0.1, 1.0 / 3.0, 2.718281828459045, 9.0, 7.5])
+    n = SqlStore(Conn, "%s").write_term_statistics(terms, df, idf, 123.456, np.array([5, 1, 2, 0, 0]), extra_term_rows=np.array([0, 0, 0, 0, 4]))
+    assert n == 4                                     # "norows" has no token rows at all
+    kinds = [e[0] for e in log]
+    assert kinds[0] == "sql" and log[0][1].startswith("TRUNCATE") and kinds[1] == "copy" and kinds[-1] == "commit"
+    text = b"".join(e[1] for e in log if e[0] == "data").decode()
+    rows = [line.split("\t") for line in text.splitlines()]
+    unesc = lambda v: v.replace("\\t", "\t").replace("\\\\", "\\")  # noqa: E731
+    assert [unesc(r[0]) for r in rows] == ["alpha", "tab\there", "back\\slash", "orphan"]
+    assert [int(r[1]) for r in rows] == [3, 1, 2, 0]
+    assert [float(r[2]) for r in rows] == [0.1, 1.0 / 3.0, 2.718281828459045, 7.5] and {float(r[3]) for r in rows} == {123.456}
