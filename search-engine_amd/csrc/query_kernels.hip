@@ -208,37 +208,40 @@ struct TopK {
         }
     }
 
+    // the lanes with p set append their candidates to the waiting slots
+    __device__ __forceinline__ void store(bool p, bool lazy, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm) {
+        const uint64_t m = __ballot(p);
+        if (p) {
+            const uint32_t pos = S + np + (uint32_t)__popcll(m & lanemask_lt());
+            key[pos] = ck;
+            if (HAS_TIE && !LAZY_ONLY && !lazy) tie_[pos] = ct;
+            unit[pos] = cu;
+            mat[pos] = (unsigned char)cm;
+        }
+        np += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool passes(bool has, bool lazy, uint64_t ck, uint32_t ct) const {
+        return has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie));
+    }
+
     // every lane may offer one candidate; wave-uniform control flow
     __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
         const bool lazy = LAZY_ONLY || (HAS_TIE && lazy_rank != nullptr);
-        auto passes = [&] { return has && (lazy ? ck >= thr_key : better(ck, ct, thr_key, thr_tie)); };
-        auto store = [&](bool p) {  // the lanes with p set append their candidates to the waiting slots
-            const uint64_t m = __ballot(p);
-            if (p) {
-                const uint32_t pos = S + np + (uint32_t)__popcll(m & lanemask_lt());
-                key[pos] = ck;
-                if (HAS_TIE && !LAZY_ONLY && !lazy) tie_[pos] = ct;
-                unit[pos] = cu;
-                mat[pos] = (unsigned char)cm;
-            }
-            np += (uint32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
-        };
-        bool pass = passes();
+        bool pass = passes(has, lazy, ck, ct);
         uint64_t pm = __ballot(pass);
         if (pm == 0) return;
         if (np + (uint32_t)__popcll(pm) > W) {
             cut(k);
-            pass = passes();
+            pass = passes(has, lazy, ck, ct);
             pm = __ballot(pass);
         }
         if (W < 64 && (uint32_t)__popcll(pm) > W) {  // more than the (now empty) waiting slots take: the lower lanes first
-            store(pass && lane_id() < 32u);
+            store(pass && lane_id() < 32u, lazy, ck, ct, cu, cm);
             cut(k);
-            has = has && lane_id() >= 32u;
-            pass = passes();
+            pass = passes(has && lane_id() >= 32u, lazy, ck, ct);
         }
-        store(pass);
+        store(pass, lazy, ck, ct, cu, cm);
     }
 
     __device__ void write_out(uint32_t k, uint32_t* o_unit, double* o_score, uint32_t* o_mat, uint32_t* o_tie,
@@ -955,19 +958,21 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     // registers (without the filter on the middle lists a two-chunk step would overfill the table most of the time)
     // candidates in registers: the longest list, which sets most frontiers, holds blocks of four chunks (256 slots per
     // step), the shorter lists blocks of two (what they bring in a step must fit the table)
-    constexpr int BLK = STEP_BLOCK, BLK_L = T <= 4 ? 2 * STEP_BLOCK : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 4 : STEP_WAVES;
+    constexpr int BLK = STEP_BLOCK, BLK_L = T <= 4 ? 2 * STEP_BLOCK : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 3 : (T == 4 ? 5 : STEP_WAVES);  // register budgets that need no spills
+    // longest-list blocks with the candidates in LDS (measured per buffer size: registers against waves per CU)
+    constexpr int BLK_192_L = T > 4 ? 1 : 3, BLK_304_L = T > 4 ? 1 : 4;
     if (b.k <= 48) {
         hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS, BLK_L>), grid, block, 0, st, b);
         return;
     }
     if constexpr (T <= 4) {
         if (b.k <= 128) {
-            hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+            hipLaunchKernelGGL((k_score_step<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID, BLK_192_L>), grid, block, 0, st, b);
             return;
         }
     }
     if (b.k <= 256) {
-        hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID, BLK_304_L>), grid, block, 0, st, b);
         return;
     }
     if constexpr (T <= 4) {  // candidate storage sized to k: the waves a CU holds fall with it (11, 7, 4 at three lists)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../../search-engine_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
 for f in abi build_kernels query_kernels update_kernels corpus_gen; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function "$@" -c $f.hip -o $tmp/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=1000000 "$@" -c $f.hip -o $tmp/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/lib/libsebm25_$name.so $tmp/*.o
