@@ -954,13 +954,11 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 template <int T, bool HAS_RANK>
 static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    // more than four lists: only three sizes of candidate storage; with the candidates in LDS one chunk per list in
-    // registers (without the filter on the middle lists a two-chunk step would overfill the table most of the time)
-    // candidates in registers: the longest list, which sets most frontiers, holds blocks of four chunks (256 slots per
-    // step), the shorter lists blocks of two (what they bring in a step must fit the table)
-    constexpr int BLK = STEP_BLOCK, BLK_L = T <= 4 ? 2 * STEP_BLOCK : STEP_BLOCK, BLK_MID = T > 4 ? 1 : STEP_BLOCK_MID, WAVES = T > 4 ? 3 : (T == 4 ? 5 : STEP_WAVES);  // register budgets that need no spills
-    // longest-list blocks with the candidates in LDS (measured per buffer size: registers against waves per CU)
-    constexpr int BLK_192_L = T > 4 ? 1 : 3, BLK_304_L = T > 4 ? 1 : 4;
+    // Chunks per block: two for the lists that insert (what they bring in a step must fit the table), four for the
+    // longest list, which sets most frontiers (three with the 192-entry candidate buffer: measured).  More than four
+    // lists: only three sizes of candidate storage.  The waves asked for leave every instantiation without spills.
+    constexpr int BLK = STEP_BLOCK, BLK_L = 2 * STEP_BLOCK, BLK_MID = STEP_BLOCK_MID, BLK_192_L = 3, BLK_304_L = 4;
+    constexpr int WAVES = T > 4 ? 3 : (T == 4 ? 5 : STEP_WAVES), WAVES_MID = T > 4 ? 2 : STEP_WAVES_MID;
     if (b.k <= 48) {
         hipLaunchKernelGGL((k_score_step<T, RegTopK<HAS_RANK>, HAS_RANK, WAVES, BLK, STEP_SLOTS, BLK_L>), grid, block, 0, st, b);
         return;
@@ -972,7 +970,7 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
         }
     }
     if (b.k <= 256) {
-        hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, STEP_WAVES_MID, BLK_MID, STEP_SLOTS_MID, BLK_304_L>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((k_score_step<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, WAVES_MID, BLK_MID, STEP_SLOTS_MID, BLK_304_L>), grid, block, 0, st, b);
         return;
     }
     if constexpr (T <= 4) {  // candidate storage sized to k: the waves a CU holds fall with it (11, 7, 4 at three lists)
