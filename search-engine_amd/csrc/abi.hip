@@ -68,6 +68,7 @@ struct sebm25_index {
     // ---- incremental updates.  The handle itself is the base segment; every sebm25_update adds one more
     // (a handle of its own that only the base refers to).  A unit's live rows are in exactly one segment.
     std::vector<sebm25_index*> deltas;
+    std::vector<sebm25_index*> spares;   // segment objects of dropped update segments, kept with their device buffers for the next update
     DevBuf dead_web, dead_news;  // bitmaps over this segment's unit spaces: rows of these units are dead here
     bool has_dead = false;
     uint64_t dead_rows = 0;
@@ -333,9 +334,38 @@ int refresh_host_ptrs(sebm25_index* ix) {
     return SEBM25_OK;
 }
 
+// Update segments that are dropped keep their (grow-only) device buffers for the next update: freeing and
+// allocating the fifteen buffers of a segment costs more than building a small segment does.
+constexpr size_t SPARE_SEGMENTS = 8, SPARE_MAX_BYTES = (size_t)256 << 20;
 void drop_deltas(sebm25_index* ix) {
-    for (sebm25_index* d : ix->deltas) sebm25_destroy(d);
+    for (sebm25_index* d : ix->deltas) {
+        if (ix->spares.size() < SPARE_SEGMENTS && d->sortA.cap <= SPARE_MAX_BYTES && d->deltas.empty()) {
+            d->built = d->finalized = false;
+            d->has_dead = false;
+            d->dead_rows = 0;
+            d->sorted_rows = nullptr;
+            d->host_ptrs_valid = false;
+            ix->spares.push_back(d);
+        } else {
+            sebm25_destroy(d);
+        }
+    }
     ix->deltas.clear();
+}
+sebm25_index* take_segment(sebm25_index* ix) {
+    sebm25_index* seg = nullptr;
+    if (!ix->spares.empty()) {
+        seg = ix->spares.back();
+        ix->spares.pop_back();
+    } else {
+        seg = new (std::nothrow) sebm25_index();
+    }
+    if (seg) {
+        seg->device = ix->device;
+        seg->stream = ix->stream;
+        seg->sort_bits = ix->sort_bits;
+    }
+    return seg;
 }
 
 int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_totals* tg) {
@@ -363,7 +393,9 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
 // Sorts the rows of a segment and writes its posting slots, list bounds, df and row counts.  The rows are the
 // caller's raw arrays (start_packed == nullptr) or packed rows that already sit in sort buffer A (compaction).
 // ix->R / V / fmt / n_docs / n_articles describe the segment; buffers are sized here.
-int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, bool unit_major, const uint8_t* flags_dev) {
+// presorted: start_packed (sort buffer A) already holds the rows in their final order; only the postings are made
+int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, bool unit_major, const uint8_t* flags_dev,
+                  bool presorted = false) {
     const uint64_t R = ix->R;
     const uint32_t V = ix->V;
     const RowFmt fmt = ix->fmt;
@@ -393,7 +425,7 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
         // ---- stable LSD radix sort on the key bits of the packed row
         const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
         const int key_bits = 64 - key_lo;
-        const int n_pass = (key_bits + ix->sort_bits - 1) / ix->sort_bits;
+        const int n_pass = presorted ? 0 : (key_bits + ix->sort_bits - 1) / ix->sort_bits;
         ix->n_pass = (uint32_t)n_pass;
         // one chunk = one tile = the work of one scatter workgroup
         const uint64_t chunk_rows = SORT_TILE;
@@ -675,11 +707,8 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
 
     lap("bitmaps");
     // ---- the new rows become a segment of their own (nothing that exists is touched until this has succeeded)
-    sebm25_index* seg = new (std::nothrow) sebm25_index();
+    sebm25_index* seg = take_segment(ix);
     if (!seg) return fail(ix, SEBM25_E_NOMEM, "update: out of host memory");
-    seg->device = ix->device;
-    seg->stream = ix->stream;
-    seg->sort_bits = ix->sort_bits;
     rc = do_build_local(seg, in);
     uint32_t listed_err = 0;
     if (!rc && seg->R) {
@@ -779,25 +808,71 @@ int do_compact(sebm25_index* ix) {
     int rc;
     for (sebm25_index* g : segs)
         if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
-    // ---- the live rows of every segment, in the common row format, into a new sort buffer
+    // ---- the live rows of the update segments, in the common row format, sorted among themselves (they are few)
+    uint64_t n_upd = 0;
+    for (size_t s = 1; s < segs.size(); ++s) n_upd += segs[s]->R - segs[s]->dead_rows;
+    sebm25_index* tmp = nullptr;
+    struct TmpGuard {
+        sebm25_index*& p;
+        std::vector<sebm25_index*>& spares;
+        ~TmpGuard() {
+            if (!p) return;
+            if (spares.size() < SPARE_SEGMENTS && p->sortA.cap <= SPARE_MAX_BYTES) spares.push_back(p); else sebm25_destroy(p);
+        }
+    } tmp_guard{tmp, ix->spares};
+    const uint64_t* upd_rows = nullptr;
+    HIP_TRY(ix, ix->upd_counts.ensure(64));
+    if (n_upd) {
+        tmp = take_segment(ix);
+        if (!tmp) return fail(ix, SEBM25_E_NOMEM, "compact: out of host memory");
+        tmp->R = n_upd; tmp->V = ix->V_cur; tmp->n_docs = ix->n_docs_cur; tmp->n_articles = ix->n_articles_cur; tmp->fmt = fmt;
+        HIP_TRY(ix, tmp->scalars.ensure(64));
+        HIP_TRY(ix, hipMemsetAsync(tmp->scalars.p, 0, 64, ix->stream));
+        HIP_TRY(ix, tmp->sortA.ensure((n_upd + POST_PAD) * 8));
+        HIP_TRY(ix, hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream));
+        for (size_t s = 1; s < segs.size(); ++s) {
+            sebm25_index* g = segs[s];
+            launch_gather_live(g->sorted_rows, g->R, g->fmt, fmt, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(),
+                               tmp->sortA.as<uint64_t>(), ix->upd_counts.as<unsigned long long>(), ix->stream);
+        }
+        HIP_TRY(ix, hipGetLastError());
+        unsigned long long got = 0;
+        HIP_TRY(ix, hipMemcpyAsync(&got, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+        if (got != n_upd) return fail(ix, SEBM25_E_INTERNAL, "compact: live row count of the update segments disagrees with their bookkeeping");
+        if ((rc = sort_and_post(tmp, RawRows{}, tmp->sortA.as<uint64_t>(), false, nullptr))) return fail(ix, rc, tmp->err);
+        upd_rows = tmp->sorted_rows;
+    }
+    // ---- merge: the base segment's rows are sorted already.  Live rows per tile, their running sum, the insertion
+    // point of every update row, then one pass that writes both to their merged places.
     // The base segment's sorted rows sit in one of its two sort buffers and its posting slots in the other; the
-    // slots are rebuilt anyway, so their buffer takes the gathered rows when it is large enough (no allocation).
+    // slots are rebuilt anyway, so their buffer takes the merged rows when it is large enough (no allocation).
     const size_t cap = std::max<uint64_t>(total, 1);
     const size_t need = (cap + POST_PAD) * 8;
     DevBuf* slot_buf = ix->sorted_rows == ix->sortA.as<uint64_t>() ? &ix->sortB : &ix->sortA;
     DevBuf nA;
     const bool in_place = ix->sorted_rows && slot_buf->cap >= need;
     if (!in_place) HIP_TRY(ix, nA.ensure(need));
-    uint64_t* gathered = in_place ? slot_buf->as<uint64_t>() : nA.as<uint64_t>();
-    HIP_TRY(ix, ix->upd_counts.ensure(64));
-    hipError_t e = hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream);
-    for (sebm25_index* g : segs)
-        launch_gather_live(g->sorted_rows, g->R, g->fmt, fmt, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(),
-                           gathered, ix->upd_counts.as<unsigned long long>(), ix->stream);
-    unsigned long long n_live = 0;
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&n_live, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream);
+    uint64_t* merged = in_place ? slot_buf->as<uint64_t>() : nA.as<uint64_t>();
+    const uint32_t n_tiles = merge_tiles_for(ix->R);
+    hipError_t e = ix->chunk_hist.ensure(((size_t)n_tiles + 1) * 4);
+    if (e == hipSuccess) e = ix->scan_tmp.ensure(scan_tmp_words((size_t)n_tiles + 1) * 4);
+    if (e == hipSuccess) e = ix->upd_ids.ensure(std::max<uint64_t>(n_upd, 1) * 4);
+    uint32_t* tile_off = ix->chunk_hist.as<uint32_t>();
+    uint32_t* ins = ix->upd_ids.as<uint32_t>();
+    uint32_t live_base = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(tile_off + n_tiles, 0, 4, ix->stream);
+    if (e == hipSuccess) {
+        launch_live_tile_counts(ix->sorted_rows, ix->R, ix->fmt, ix->dead_web.as<uint32_t>(), ix->dead_news.as<uint32_t>(), tile_off, ix->stream);
+        launch_exclusive_scan_u32(tile_off, (size_t)n_tiles + 1, ix->scan_tmp.as<uint32_t>(), ix->stream);
+        launch_insert_points(upd_rows, n_upd, fmt, ix->sorted_rows, ix->R, ix->fmt, ins, ix->stream);
+        launch_merge_tiles(ix->sorted_rows, ix->R, ix->fmt, ix->dead_web.as<uint32_t>(), ix->dead_news.as<uint32_t>(), tile_off, upd_rows,
+                           n_upd, ins, fmt, merged, ix->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&live_base, tile_off + n_tiles, 4, hipMemcpyDeviceToHost, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    const unsigned long long n_live = (unsigned long long)live_base + n_upd;
     if (e != hipSuccess || n_live != total) {
         nA.release();
         ix->built = ix->built && !in_place;  // the slots of the base segment were overwritten
@@ -821,8 +896,8 @@ int do_compact(sebm25_index* ix) {
     phases_reset(ix);
     uint64_t* scal = ix->scalars.as<uint64_t>();
     HIP_TRY(ix, hipMemsetAsync(scal, 0, 64, ix->stream));
-    // sort_and_post sizes buffer B; buffer A already holds the rows (ensure keeps a buffer that is large enough)
-    if ((rc = sort_and_post(ix, RawRows{}, ix->sortA.as<uint64_t>(), false, nullptr))) {
+    // sort_and_post sizes buffer B; buffer A already holds the rows in order (ensure keeps a buffer that is large enough)
+    if ((rc = sort_and_post(ix, RawRows{}, ix->sortA.as<uint64_t>(), false, nullptr, true))) {
         ix->built = false;
         return rc;
     }
@@ -882,6 +957,8 @@ void sebm25_destroy(sebm25_index* ix) {
     if (!ix) return;
     for (sebm25_index* d : ix->deltas) sebm25_destroy(d);
     ix->deltas.clear();
+    for (sebm25_index* d : ix->spares) sebm25_destroy(d);
+    ix->spares.clear();
     {
         DeviceGuard g(ix->device);
         (void)hipStreamSynchronize(ix->stream);

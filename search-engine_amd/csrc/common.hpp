@@ -156,6 +156,15 @@ void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uin
                          uint32_t* err, hipStream_t st);
 void launch_doc_len_merge(uint32_t* doc_len, const uint32_t* new_len, const uint32_t* chg_web, uint32_t n_docs, hipStream_t st);
 void launch_add_u32(uint32_t* dst, const uint32_t* src, uint32_t n, hipStream_t st);
+// compaction by merging: live rows per tile of base rows, insertion points of the (sorted) update rows, the merge
+uint32_t merge_tiles_for(uint64_t R);
+void launch_live_tile_counts(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* dead_web, const uint32_t* dead_news,
+                             uint32_t* counts, hipStream_t st);
+void launch_insert_points(const uint64_t* upd, uint64_t n_upd, RowFmt ufmt, const uint64_t* base, uint64_t R, RowFmt bfmt, uint32_t* ip,
+                          hipStream_t st);
+void launch_merge_tiles(const uint64_t* base, uint64_t R, RowFmt bfmt, const uint32_t* dead_web, const uint32_t* dead_news,
+                        const uint32_t* tile_off, const uint64_t* upd, uint64_t n_upd, const uint32_t* ip, RowFmt to, uint64_t* out,
+                        hipStream_t st);
 void launch_gather_live(const uint64_t* rows, uint64_t R, RowFmt from, RowFmt to, const uint32_t* dead_web,
                         const uint32_t* dead_news, uint64_t* out, unsigned long long* n_out, hipStream_t st);
 

@@ -175,6 +175,137 @@ __global__ __launch_bounds__(256) void k_gather_live(const uint64_t* rows, uint3
     }
 }
 
+// ---- compaction by merging --------------------------------------------------------------------------------
+// The base segment's rows are sorted and so are (after a sort of their own) the few live rows of the update
+// segments; a unit's live rows sit in one segment only, so no live row of one side compares equal to a live row
+// of the other.  The merged position of a base row is therefore
+//   (live base rows before it) + (update rows whose key is smaller),
+// and of update row j:  j + (live base rows before its insertion point).  Rows compare on (term, source, unit),
+// the sort key of every segment, decoded from whichever row format the segment has.
+constexpr uint32_t MERGE_TILE = 4096, MERGE_THREADS = 1024, MERGE_ITEMS = MERGE_TILE / MERGE_THREADS;
+
+__device__ __forceinline__ uint64_t merge_key(RowFmt f, uint64_t r) {
+    return ((uint64_t)((f.term(r) << 1) | f.src(r)) << 32) | f.unit(r);
+}
+
+// live rows per tile of MERGE_TILE base rows (tiles run to index R inclusive: a row that does not exist is dead)
+__global__ __launch_bounds__(MERGE_THREADS) void k_live_tile_counts(const uint64_t* rows, uint32_t R, RowFmt fmt, const uint32_t* dead_web,
+                                                                    const uint32_t* dead_news, uint32_t* counts) {
+    __shared__ uint32_t wsum[MERGE_THREADS / 64];
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < MERGE_ITEMS; ++k) {  // any order will do for a count: consecutive lanes, consecutive rows
+        const uint64_t i = (uint64_t)blockIdx.x * MERGE_TILE + k * MERGE_THREADS + threadIdx.x;
+        if (i < R) {
+            const uint64_t r = rows[i];
+            n += bit_of(fmt.src(r) ? dead_news : dead_web, fmt.unit(r)) ? 0u : 1u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += (uint32_t)__shfl_xor((int)n, o);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < MERGE_THREADS / 64; ++w) t += wsum[w];
+        counts[blockIdx.x] = t;
+    }
+}
+
+// insertion point of every update row: the first base index whose key is not smaller (dead base rows keep their
+// keys and their places, so the search runs over all R of them)
+__global__ __launch_bounds__(256) void k_insert_points(const uint64_t* upd, uint32_t n_upd, RowFmt ufmt, const uint64_t* base, uint32_t R,
+                                                       RowFmt bfmt, uint32_t* ip) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_upd) return;
+    const uint64_t key = merge_key(ufmt, upd[j]);
+    uint32_t lo = 0, hi = R;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (merge_key(bfmt, base[mid]) < key) lo = mid + 1; else hi = mid;
+    }
+    ip[j] = lo;
+}
+
+// one workgroup per tile of base rows: writes the tile's live rows (repacked) and the update rows that are
+// inserted inside the tile to their merged places.  tile_off: live base rows before the tile (exclusive scan of
+// k_live_tile_counts).
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(const uint64_t* base, uint32_t R, RowFmt bfmt, const uint32_t* dead_web,
+                                                               const uint32_t* dead_news, const uint32_t* tile_off, const uint64_t* upd,
+                                                               uint32_t n_upd, const uint32_t* ip, RowFmt to, uint64_t* out) {
+    __shared__ uint32_t mark[MERGE_TILE];          // update rows inserted at each base index of the tile
+    __shared__ unsigned short live_before[MERGE_TILE];
+    __shared__ uint32_t wl[MERGE_THREADS / 64], wd[MERGE_THREADS / 64];
+    __shared__ uint32_t range[2];
+    const uint64_t a = (uint64_t)blockIdx.x * MERGE_TILE;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t < 2) {  // update rows with an insertion point in [a, a + MERGE_TILE): rows range[0] .. range[1] - 1
+        const uint64_t x = a + (t ? MERGE_TILE : 0u);
+        uint32_t lo = 0, hi = n_upd;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint64_t)ip[mid] < x) lo = mid + 1; else hi = mid;
+        }
+        range[t] = lo;
+    }
+    for (uint32_t x = t; x < MERGE_TILE; x += MERGE_THREADS) mark[x] = 0;
+    __syncthreads();
+    const uint32_t c0 = range[0], c1 = range[1];
+    for (uint32_t j = c0 + t; j < c1; j += MERGE_THREADS) atomicAdd(&mark[ip[j] - (uint32_t)a], 1u);
+    __syncthreads();
+    // thread t owns base rows a + MERGE_ITEMS t ... (consecutive, so prefix sums run in row order)
+    uint64_t r[MERGE_ITEMS];
+    bool live[MERGE_ITEMS];
+    uint32_t m[MERGE_ITEMS], sl = 0, sd = 0;
+    static_assert(MERGE_ITEMS == 4, "two 16-byte loads per thread");
+    const uint64_t i_first = a + (uint64_t)t * MERGE_ITEMS;
+    if (i_first + MERGE_ITEMS <= R) {  // (the rows start at a multiple of 32 bytes: the buffers are 256-byte aligned)
+        const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(base + i_first), hi = *reinterpret_cast<const ulonglong2*>(base + i_first + 2);
+        r[0] = lo.x; r[1] = lo.y; r[2] = hi.x; r[3] = hi.y;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < MERGE_ITEMS; ++k) r[k] = i_first + k < R ? base[i_first + k] : 0ull;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < MERGE_ITEMS; ++k) {
+        live[k] = i_first + k < R && !bit_of(bfmt.src(r[k]) ? dead_news : dead_web, bfmt.unit(r[k]));
+        m[k] = mark[t * MERGE_ITEMS + k];
+        sl += live[k] ? 1u : 0u;
+        sd += m[k];
+    }
+    uint32_t il = sl, id = sd;  // inclusive scans over the wave, then over the waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t xl = (uint32_t)__shfl_up((int)il, o), xd = (uint32_t)__shfl_up((int)id, o);
+        if ((int)lane >= o) {
+            il += xl;
+            id += xd;
+        }
+    }
+    if (lane == 63) {
+        wl[wave] = il;
+        wd[wave] = id;
+    }
+    __syncthreads();
+    uint32_t el = il - sl, ed = id - sd;  // exclusive, within the tile
+    for (uint32_t w = 0; w < wave; ++w) {
+        el += wl[w];
+        ed += wd[w];
+    }
+    const uint32_t off = tile_off[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < MERGE_ITEMS; ++k) {
+        live_before[t * MERGE_ITEMS + k] = (unsigned short)el;
+        ed += m[k];  // update rows inserted at or before this row come first
+        if (live[k]) {
+            out[(uint64_t)off + el + c0 + ed] = to.pack(bfmt.term(r[k]), bfmt.src(r[k]), bfmt.unit(r[k]), bfmt.fc(r[k]), bfmt.tf(r[k]));
+            ++el;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = c0 + t; j < c1; j += MERGE_THREADS) out[(uint64_t)j + off + live_before[ip[j] - (uint32_t)a]] = upd[j];
+}
+
 }  // namespace
 
 static inline dim3 grid_for(uint64_t n, int threads, int cap = 8192) {
@@ -215,6 +346,23 @@ void launch_gather_live(const uint64_t* rows, uint64_t R, RowFmt from, RowFmt to
     if (R == 0) return;
     hipLaunchKernelGGL(k_gather_live, grid_for(R, 256), dim3(256), 0, st, rows, (uint32_t)R, from, to, dead_web, dead_news, out,
                        n_out);
+}
+
+uint32_t merge_tiles_for(uint64_t R) { return (uint32_t)((R + MERGE_TILE) / MERGE_TILE); }  // index R included
+void launch_live_tile_counts(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* dead_web, const uint32_t* dead_news,
+                             uint32_t* counts, hipStream_t st) {
+    hipLaunchKernelGGL(k_live_tile_counts, dim3(merge_tiles_for(R)), dim3(MERGE_THREADS), 0, st, rows, (uint32_t)R, fmt, dead_web, dead_news, counts);
+}
+void launch_insert_points(const uint64_t* upd, uint64_t n_upd, RowFmt ufmt, const uint64_t* base, uint64_t R, RowFmt bfmt, uint32_t* ip,
+                          hipStream_t st) {
+    if (n_upd == 0) return;
+    hipLaunchKernelGGL(k_insert_points, dim3((unsigned)((n_upd + 255) / 256)), dim3(256), 0, st, upd, (uint32_t)n_upd, ufmt, base, (uint32_t)R, bfmt, ip);
+}
+void launch_merge_tiles(const uint64_t* base, uint64_t R, RowFmt bfmt, const uint32_t* dead_web, const uint32_t* dead_news,
+                        const uint32_t* tile_off, const uint64_t* upd, uint64_t n_upd, const uint32_t* ip, RowFmt to, uint64_t* out,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_merge_tiles, dim3(merge_tiles_for(R)), dim3(MERGE_THREADS), 0, st, base, (uint32_t)R, bfmt, dead_web, dead_news, tile_off,
+                       upd, (uint32_t)n_upd, ip, to, out);
 }
 
 }  // namespace sebm25

@@ -173,6 +173,39 @@ def test_update_batches_equal_full_rebuild(gpu_index_factory):
     assert_same_index(upd, ref, tb, rng, hot)
 
 
+def test_update_and_compaction_cycles_reuse_segment_storage(gpu_index_factory):
+    """Several cycles of updates and compactions on one handle: the storage of dropped segments is used again, a
+    compaction may find nothing but dead rows to drop (units removed, none added), one or many update segments to
+    merge, grown term / doc id spaces (the rows are repacked); after each the index equals a full rebuild."""
+    rng = np.random.default_rng(77)
+    c = O.gen_corpus(O.make_spec(n_terms=2500, n_docs=5000, n_articles=300))   # several merge tiles of base rows
+    tb = Table(c)
+    hot = np.arange(10, 50)
+    upd, ref = gpu_index_factory(), gpu_index_factory()
+    full_build(upd, tb)
+    for cycle, n_batches in enumerate((1, 3, 0, 5, 2)):
+        if n_batches == 0:                              # removal only: docs and articles disappear, no rows arrive
+            cd = sorted(set(rng.integers(0, tb.n_docs, 40).tolist()))
+            ca = sorted(set(rng.integers(0, tb.n_articles, 10).tolist()))
+            for d in cd:
+                tb.docs.pop(d, None)
+                tb.flags[d], tb.word_count[d] = 0, 0
+            for a in ca:
+                tb.arts.pop(a, None)
+            z = np.zeros(0, np.uint32)
+            upd.update(z, z, z, np.zeros(0, np.uint8), tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags,
+                       changed_docs=cd, changed_articles=ca)
+        for _ in range(n_batches):
+            cd, ca = apply_random_batch(rng, tb, hot)
+            t, u, f, m = tb.arrays(cd, ca)
+            upd.update(t, u, f, m, tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=cd, changed_articles=ca)
+        upd.compact()
+        inf = upd.info()
+        assert inf.n_segments == 1 and inf.n_dead_rows == 0, cycle
+        full_build(ref, tb)
+        assert_same_index(upd, ref, tb, rng, hot, k_list=(10,))
+
+
 def test_update_rejects_rows_of_units_that_are_not_listed(gpu_index_factory):
     c = O.gen_corpus(O.make_spec(n_terms=500, n_docs=100))
     tb = Table(c)
