@@ -97,6 +97,43 @@ def test_missing_idf_is_one_and_url_rank_breaks_ties(built):
         orc.set_idf(orc.idf)
 
 
+@pytest.mark.parametrize("tpq", [1, 3, 4, 6, 10])
+def test_url_ranks_with_every_size_of_candidate_storage(built, tpq):
+    """An explicit rank array (ties break on it, not on the unit id) through every kernel variant: candidates in
+    registers, in the LDS buffers whose tie-break keys are read when the buffer is cut, and the general kernel;
+    queries of rare terms (many exact score ties at the cut) and of frequent ones."""
+    c, orc, ix = built
+    V = c["n_terms"]
+    rng = np.random.default_rng(100 + tpq)
+    rank = rng.permutation(c["n_docs"]).astype(np.uint32)
+    try:
+        ix.set_url_rank(se.SRC_WEB, rank)
+        qs = _queries(V, 12, tpq, min_rank=300, seed=5 + tpq) + _queries(V, 12, tpq, min_rank=2, seed=50 + tpq)
+        for k in (10, 48, 60, 128, 210, 300, 700, 2000):
+            out = ix.search(qs, k)
+            for qi, q in enumerate(qs):
+                ru, rs, rm = orc.search(q, k, url_rank=rank, level="csr")
+                n = int(out["count"][qi])
+                assert n == len(ru)
+                np.testing.assert_array_equal(out["unit"][qi, :n], ru, err_msg=f"k {k} query {qi}")
+                np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+                np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+        # the news segment with a rank array of its own
+        rank_n = rng.permutation(c["n_articles"]).astype(np.uint32)
+        ix.set_url_rank(se.SRC_NEWS, rank_n)
+        for k in (10, 210):
+            out = ix.search(qs, k, source=se.SRC_NEWS)
+            for qi, q in enumerate(qs):
+                ru, rs, rm = orc.search(q, k, source=se.SRC_NEWS, url_rank=rank_n, level="csr")
+                n = int(out["count"][qi])
+                assert n == len(ru)
+                np.testing.assert_array_equal(out["unit"][qi, :n], ru, err_msg=f"news k {k} query {qi}")
+                np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+    finally:
+        ix.set_url_rank(se.SRC_WEB, None)
+        ix.set_url_rank(se.SRC_NEWS, None)
+
+
 def test_sliced_long_queries_equal_unsliced(gpu_index_factory):
     # head terms over a larger corpus force the unit-range split + merge path
     c = small_corpus(n_docs=40_000, n_terms=3000, body_min=20, body_max=60, title_len=2, desc_len=4)
