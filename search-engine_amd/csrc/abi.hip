@@ -84,6 +84,9 @@ struct sebm25_index {
     // search scratch
     DevBuf q_items, q_terms, q_first, q_n;
     DevBuf o_unit, o_score, o_mat, o_tie, o_count, t_unit, t_score, t_mat, t_tie, t_count;
+    DevBuf o_pack;                 // small host-bound results: all five arrays in one buffer, one copy back
+    void* o_host = nullptr;        // its pinned host twin (grow-only)
+    size_t o_host_cap = 0;
     DevBuf m_in[5];
     DevBuf gen_rows, gen_cdf;
 
@@ -969,12 +972,13 @@ void sebm25_destroy(sebm25_index* ix) {
                          &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
                          &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
                          &ix->st_flags, &ix->st_misc, &ix->url_rank_web, &ix->url_rank_news, &ix->q_items, &ix->q_terms,
-                         &ix->q_first, &ix->q_n, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
+                         &ix->q_first, &ix->q_n, &ix->o_pack, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
                          &ix->t_score, &ix->t_mat, &ix->t_tie, &ix->t_count, &ix->m_in[0], &ix->m_in[1], &ix->m_in[2],
                          &ix->m_in[3], &ix->m_in[4], &ix->gen_rows, &ix->gen_cdf};
         for (DevBuf* b : all) b->release();
         for (hipEvent_t e : ix->timer.ev) (void)hipEventDestroy(e);
         if (ix->na_host) (void)hipHostFree(ix->na_host);
+        if (ix->o_host) (void)hipHostFree(ix->o_host);
     }
     delete ix;
 }
@@ -1671,7 +1675,27 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(info.n_tmp, 1u) * 4));
     uint32_t *d_unit = out_unit, *d_mat = out_matched, *d_count = out_count, *d_tie = out_tie;
     double* d_score = out_score;
-    if (!dev_out) {
+    // results bound for host arrays, when small: the five arrays sit in one device buffer and come back with one
+    // copy into pinned memory (five copies into pageable memory cost more than scoring a single query does)
+    const size_t pack_bytes = qk * 8 + qk * 4 * (out_tie ? 3 : 2) + (size_t)n_queries * 4;
+    const bool packed = !dev_out && pack_bytes <= ((size_t)256 << 10);
+    if (packed) {
+        HIP_TRY(ix, ix->o_pack.ensure(pack_bytes));
+        if (ix->o_host_cap < pack_bytes) {
+            if (ix->o_host) (void)hipHostFree(ix->o_host);
+            ix->o_host = nullptr;
+            ix->o_host_cap = 0;
+            const size_t want = std::max<size_t>(pack_bytes, (size_t)64 << 10);
+            HIP_TRY(ix, hipHostMalloc(&ix->o_host, want, hipHostMallocDefault));
+            ix->o_host_cap = want;
+        }
+        unsigned char* p = static_cast<unsigned char*>(ix->o_pack.p);
+        d_score = reinterpret_cast<double*>(p);
+        d_unit = reinterpret_cast<uint32_t*>(p + qk * 8);
+        d_mat = d_unit + qk;
+        d_tie = out_tie ? d_mat + qk : nullptr;
+        d_count = (out_tie ? d_tie : d_mat) + qk;
+    } else if (!dev_out) {
         HIP_TRY(ix, ix->o_unit.ensure(qk * 4));
         HIP_TRY(ix, ix->o_score.ensure(qk * 8));
         HIP_TRY(ix, ix->o_mat.ensure(qk * 4));
@@ -1693,6 +1717,17 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
     else
         rc = run_search(ix, news, n_queries, k, st, info, b, d_unit, d_score, d_mat, d_tie, d_count);
     if (rc) return rc;
+    if (packed) {
+        HIP_TRY(ix, hipMemcpyAsync(ix->o_host, ix->o_pack.p, pack_bytes, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+        const unsigned char* h = static_cast<const unsigned char*>(ix->o_host);
+        memcpy(out_score, h, qk * 8);
+        memcpy(out_unit, h + qk * 8, qk * 4);
+        memcpy(out_matched, h + qk * 12, qk * 4);
+        if (out_tie) memcpy(out_tie, h + qk * 16, qk * 4);
+        memcpy(out_count, h + qk * (out_tie ? 20 : 16), (size_t)n_queries * 4);
+        return SEBM25_OK;
+    }
     if (!dev_out) {
         if ((rc = copy_out(ix, out_unit, d_unit, qk * 4))) return rc;
         if ((rc = copy_out(ix, out_score, d_score, qk * 8))) return rc;
