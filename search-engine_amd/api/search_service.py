@@ -15,6 +15,7 @@ serves other requests is never blocked (ctypes releases the GIL).
 from __future__ import annotations
 
 import asyncio
+import functools
 import math
 import re
 from typing import Any
@@ -124,6 +125,17 @@ class _MicroBatcher:
                         fut.set_result(res)
 
 
+@functools.lru_cache(maxsize=1 << 18)
+def _text_features(title: str, description: str, url: str):
+    """What the intent score reads from a result's text, which is the same for every query that returns the
+    document: the normalised title / url / description, the url without separators, and the token sets of title
+    and url.  Cached per document: the regular expressions behind them were most of a request's time."""
+    url_l = (url or "").lower()
+    return (_NON_ALNUM.sub(" ", (title or "").lower()).strip(), _NON_ALNUM.sub(" ", url_l).strip(),
+            _NON_ALNUM.sub(" ", (description or "").lower()).strip(), _NON_ALNUM.sub("", url_l),
+            frozenset(TOKEN_RE.findall((title or "").lower())), frozenset(TOKEN_RE.findall(url_l)))
+
+
 class SearchService:
     def __init__(self, engine=None):
         self.engine = engine
@@ -159,16 +171,15 @@ class SearchService:
             score += (matched_terms / total_terms) * _W_COVERAGE
             if matched_terms == total_terms:
                 score += _W_ALL_TERMS
-        compact_url = _NON_ALNUM.sub("", (url or "").lower())
-        normalized = {"title": self._normalize_text(title), "url": self._normalize_text(url),
-                      "description": self._normalize_text(description)}
+        n_title, n_url, n_desc, compact_url, title_tokens, url_tokens = _text_features(title, description, url)
+        normalized = {"title": n_title, "url": n_url, "description": n_desc}
         if query_phrase:
             for field, bonus in _PHRASE_BONUS:
                 if query_phrase in normalized[field]:
                     score += bonus
         if query_compact and query_compact in compact_url:
             score += _COMPACT_URL_PHRASE
-        hits = {"title": self._count_hits(title, query_words), "url": self._count_hits(url, query_words),
+        hits = {"title": sum(w in title_tokens for w in query_words), "url": sum(w in url_tokens for w in query_words),
                 "compact_url": self._compact_word_hits(compact_url, query_words)}
         for field, per_hit, _ in _HIT_WEIGHT:
             score += hits[field] * per_hit
@@ -200,14 +211,17 @@ class SearchService:
                                   title=title, description=description, url=url)
 
     # ---- re-rank of candidate rows (search_service.py:242-309)
-    def _rank_web_rows(self, rows: list[tuple[Any, ...]], *, context: dict[str, Any]) -> list[WebSearchItem]:
-        items = []
+    def _rank_web_tuples(self, rows: list[tuple[Any, ...]], *, context: dict[str, Any]) -> list[tuple]:
+        """(-score, url, title, description) of every candidate row, best first."""
+        ranked = []
         for row in rows:
             title, description, url = row[0] or "", row[1] or "", row[2]
-            items.append(WebSearchItem(title=title, description=description, url=url,
-                                       score=self._score_row(context, row[3], row[4], title, description, url)))
-        items.sort(key=lambda it: (-it.score, it.url))
-        return items
+            ranked.append((-self._score_row(context, row[3], row[4], title, description, url), url, title, description))
+        ranked.sort(key=lambda r: (r[0], r[1]))
+        return ranked
+
+    def _rank_web_rows(self, rows: list[tuple[Any, ...]], *, context: dict[str, Any]) -> list[WebSearchItem]:
+        return [WebSearchItem(title=t, description=d, url=u, score=-s) for s, u, t, d in self._rank_web_tuples(rows, context=context)]
 
     def _news_feed_from_row(self, row: tuple[Any, ...]) -> NewsFeed | None:
         if not row[3]:
@@ -255,10 +269,12 @@ class SearchService:
         self._require_engine()
         kind, rows = await self.batcher.submit("web", context["query_terms"], context["candidate_limit"])
         if kind == "rows":
-            ranked = self._rank_web_rows(rows, context=context)
+            # every candidate is scored and ranked as in the reference; response models are made for the page only
+            ranked = self._rank_web_tuples(rows, context=context)
+            page = [WebSearchItem(title=t, description=d, url=u, score=-s) for s, u, t, d in ranked[offset: offset + limit]]
         else:   # the row text could not be decoded: score-only rows, reduced ranking (search_service.py:321-338)
             ranked = self._rank_score_only_rows(rows, context=context)
-        page = ranked[offset: offset + limit]
+            page = ranked[offset: offset + limit]
         return WebSearchResponse(results=page, count=max(len(ranked), offset + len(page)))
 
     async def perform_news_search(self, *, q: str, limit: int = 20, offset: int = 0) -> NewsSearchResponse:
