@@ -386,9 +386,10 @@ def main():
             "ms_each": last["ms_each"], "full_build_ms": median_ms,
             "segments_after": last["segments"], "dead_rows_after": last["dead_rows"], "compact_ms": last["compact_ms"],
             "first_cycle": cycles[0],
-            "note": "sebm25_update of re-crawled docs on the configuration-2 index (rows resident in HBM), then sebm25_compact "
-                    "of the base + 4 update segments, twice (the first cycle allocates the segments' storage, the second "
-                    "reuses it); correctness of both is covered by tests/test_gpu_update.py"}
+            "note": "four sebm25_update calls of re-crawled docs on the configuration-2 index (rows resident in HBM; each folds "
+                    "its rows into the one update segment), then sebm25_compact (base and update segment merged), twice: the "
+                    "first cycle allocates the segments' storage, the second reuses it; correctness of both is covered by "
+                    "tests/test_gpu_update.py"}
 
     # ---- batched scoring
     if not args.no_query:

@@ -179,9 +179,10 @@ int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base
  *     rows->word_count / doc_flags the full per-doc arrays as they are now.  A row of a unit that is
  *     not listed fails with SEBM25_E_INVALID and leaves the index as it was.
  * Afterwards df, term_rows, N, avgdl, idf, doc lengths, the postings and every search result equal
- * those of sebm25_build over the final table, bit for bit.  The new rows are held as a segment of their
- * own (at most 64 of them; a search scores every segment and merges); sebm25_compact folds all
- * segments into one.  url ranks must be set again when an update adds units; an idf override
+ * those of sebm25_build over the final table, bit for bit.  The new rows are held in an update segment beside
+ * the base segment (an update folds its rows and the live rows of the update segment that is there into one new
+ * update segment, so a search scores two segments at most and merges); sebm25_compact merges the update
+ * segment into the base.  url ranks must be set again when an update adds units; an idf override
  * (sebm25_set_idf) is replaced by the recomputed idf.  sebm25_update_local leaves the statistics to a
  * following sebm25_local_stats / sebm25_finalize (document-sharded indexes), as sebm25_build_local does.
  */
@@ -189,8 +190,8 @@ int sebm25_update(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* cha
                   const uint32_t* changed_articles, uint32_t n_changed_articles);
 int sebm25_update_local(sebm25_index* ix, const sebm25_rows* rows, const uint32_t* changed_docs, uint32_t n_changed_docs,
                         const uint32_t* changed_articles, uint32_t n_changed_articles);
-/* Rebuilds one segment from the live rows of all segments, on the device (no rows cross the host).
- * Results do not change.  The statistics stay finalized. */
+/* Makes one segment of the live rows of the base segment and the update segment (both sorted: a merge), on the
+ * device (no rows cross the host).  Results do not change.  The statistics stay finalized. */
 int sebm25_compact(sebm25_index* ix);
 
 /* Sizes of the built index. */
@@ -201,8 +202,9 @@ typedef struct sebm25_index_info {
     uint32_t n_terms, n_docs, n_articles;
     uint32_t term_bits, unit_bits, tf_bits; /* packed sort row layout of the base segment */
     uint32_t sort_passes;
-    uint32_t n_segments;      /* 1 + the update segments held since the last build or compaction */
+    uint32_t n_segments;      /* 1, or 2 while an update segment is held (since the last build or compaction) */
     uint64_t n_dead_rows;     /* rows of replaced or removed units that the segments still carry */
+    uint64_t n_update_rows;   /* rows of the update segment: every update sorts them again, so compact before they are many */
 } sebm25_index_info;
 int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
 

@@ -609,6 +609,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
 
 // ---- compaction: all segments folded into one, on the device --------------------------------
 int do_compact(sebm25_index* ix);
+int fold_deltas(sebm25_index* ix);
 
 // ---- incremental update --------------------------------------------------------------------
 std::vector<sebm25_index*> all_segments(sebm25_index* ix) {
@@ -671,7 +672,6 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     if ((n_cd && !chg_docs) || (n_ca && !chg_arts)) return fail(ix, SEBM25_E_INVALID, "update: a list of changed units is NULL");
     if (in->n_terms < ix->V_cur || in->n_docs < ix->n_docs_cur || in->n_articles < ix->n_articles_cur)
         return fail(ix, SEBM25_E_INVALID, "update: the term, doc and article id spaces can only grow");
-    if (ix->deltas.size() >= 64) return fail(ix, SEBM25_E_STATE, "update: 64 update segments are held; call sebm25_compact");
     const uint32_t n_docs = in->n_docs, n_arts = in->n_articles, V = in->n_terms;
     int rc;
     const bool dbg = getenv("SEBM25_DEBUG_TIMES") != nullptr;
@@ -790,62 +790,94 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     ix->local_totals.n_postings = P_all;
     ix->finalized = false;
     lap("document totals");
+    if (ix->deltas.size() > 1 && (rc = fold_deltas(ix))) return rc;
+    lap("update segments folded");
     return SEBM25_OK;
 }
 
 
-int do_compact(sebm25_index* ix) {
-    if (!ix->built) return fail(ix, SEBM25_E_STATE, "compact: no index built on this handle");
-    if (ix->deltas.empty() && ix->dead_rows == 0) return SEBM25_OK;
-    const std::vector<sebm25_index*> segs = all_segments(ix);
-    uint64_t total = 0;
-    for (const sebm25_index* g : segs) total += g->R - g->dead_rows;
-    if (total > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "compact: more than 2^32 - 4096 live rows");
+// row format for the id spaces as they are now
+RowFmt current_fmt(const sebm25_index* ix) {
     RowFmt fmt;
     fmt.term_bits = bits_for(ix->V_cur);
     fmt.unit_bits = bits_for(std::max<uint64_t>(std::max(ix->n_docs_cur, ix->n_articles_cur), 1));
     fmt.tf_bits = 61 - fmt.term_bits - fmt.unit_bits;
-    for (const sebm25_index* g : segs)
-        if (fmt.tf_bits < g->fmt.tf_bits && fmt.tf_bits < 32)
-            return fail(ix, SEBM25_E_RANGE, "compact: the grown id spaces leave too few bits for tf in the packed row (rebuild)");
-    int rc;
-    for (sebm25_index* g : segs)
-        if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
-    // ---- the live rows of the update segments, in the common row format, sorted among themselves (they are few)
-    uint64_t n_upd = 0;
-    for (size_t s = 1; s < segs.size(); ++s) n_upd += segs[s]->R - segs[s]->dead_rows;
-    sebm25_index* tmp = nullptr;
-    struct TmpGuard {
-        sebm25_index*& p;
-        std::vector<sebm25_index*>& spares;
-        ~TmpGuard() {
-            if (!p) return;
-            if (spares.size() < SPARE_SEGMENTS && p->sortA.cap <= SPARE_MAX_BYTES) spares.push_back(p); else sebm25_destroy(p);
-        }
-    } tmp_guard{tmp, ix->spares};
-    const uint64_t* upd_rows = nullptr;
-    HIP_TRY(ix, ix->upd_counts.ensure(64));
-    if (n_upd) {
-        tmp = take_segment(ix);
-        if (!tmp) return fail(ix, SEBM25_E_NOMEM, "compact: out of host memory");
-        tmp->R = n_upd; tmp->V = ix->V_cur; tmp->n_docs = ix->n_docs_cur; tmp->n_articles = ix->n_articles_cur; tmp->fmt = fmt;
-        HIP_TRY(ix, tmp->scalars.ensure(64));
-        HIP_TRY(ix, hipMemsetAsync(tmp->scalars.p, 0, 64, ix->stream));
-        HIP_TRY(ix, tmp->sortA.ensure((n_upd + POST_PAD) * 8));
-        HIP_TRY(ix, hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream));
-        for (size_t s = 1; s < segs.size(); ++s) {
-            sebm25_index* g = segs[s];
-            launch_gather_live(g->sorted_rows, g->R, g->fmt, fmt, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(),
-                               tmp->sortA.as<uint64_t>(), ix->upd_counts.as<unsigned long long>(), ix->stream);
-        }
-        HIP_TRY(ix, hipGetLastError());
-        unsigned long long got = 0;
-        HIP_TRY(ix, hipMemcpyAsync(&got, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
-        if (got != n_upd) return fail(ix, SEBM25_E_INTERNAL, "compact: live row count of the update segments disagrees with their bookkeeping");
-        if ((rc = sort_and_post(tmp, RawRows{}, tmp->sortA.as<uint64_t>(), false, nullptr))) return fail(ix, rc, tmp->err);
-        upd_rows = tmp->sorted_rows;
+    return fmt;
+}
+
+// The update segments become one: their live rows are gathered (repacked to the current row format), sorted and
+// turned into postings like any segment.  An update calls this, so that a search never scores more than the base
+// segment and one update segment (every further segment costs a batch its planning and launches again), and a
+// compaction, which then merges that one sorted segment into the base.
+int fold_deltas(sebm25_index* ix) {
+    if (ix->deltas.empty()) return SEBM25_OK;
+    const RowFmt fmt = current_fmt(ix);
+    if (ix->deltas.size() == 1) {
+        const sebm25_index* d = ix->deltas[0];
+        if (d->dead_rows == 0 && d->fmt.term_bits == fmt.term_bits && d->fmt.unit_bits == fmt.unit_bits) return SEBM25_OK;
     }
+    uint64_t n_upd = 0;
+    for (const sebm25_index* d : ix->deltas) {
+        n_upd += d->R - d->dead_rows;
+        if (fmt.tf_bits < d->fmt.tf_bits && fmt.tf_bits < 32)
+            return fail(ix, SEBM25_E_RANGE, "update: the grown id spaces leave too few bits for tf in the packed row (rebuild)");
+    }
+    if (n_upd > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "update: more than 2^32 - 4096 rows in the update segments (compact)");
+    int rc;
+    for (sebm25_index* d : ix->deltas)
+        if ((rc = ensure_dead_bitmaps(ix, d))) return rc;
+    sebm25_index* one = take_segment(ix);
+    if (!one) return fail(ix, SEBM25_E_NOMEM, "update: out of host memory");
+    auto give_back = [&](int code, const std::string& msg) {
+        sebm25_destroy(one);
+        return fail(ix, code, msg);
+    };
+    one->R = n_upd; one->V = one->V_cur = ix->V_cur; one->n_docs = one->n_docs_cur = ix->n_docs_cur;
+    one->n_articles = one->n_articles_cur = ix->n_articles_cur; one->fmt = fmt;
+    one->has_dead = false; one->dead_rows = 0; one->host_ptrs_valid = false;
+    one->h_row_ptr.resize((size_t)one->V + 1);
+    one->h_news_ptr.resize(one->V);
+    hipError_t e = one->scalars.ensure(64);
+    if (e == hipSuccess) e = hipMemsetAsync(one->scalars.p, 0, 64, ix->stream);
+    if (e == hipSuccess) e = one->sortA.ensure((std::max<uint64_t>(n_upd, 1) + POST_PAD) * 8);
+    if (e == hipSuccess) e = ix->upd_counts.ensure(64);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->upd_counts.p, 0, 8, ix->stream);
+    unsigned long long got = 0;
+    if (e == hipSuccess) {
+        for (sebm25_index* d : ix->deltas)
+            launch_gather_live(d->sorted_rows, d->R, d->fmt, fmt, d->dead_web.as<uint32_t>(), d->dead_news.as<uint32_t>(),
+                               one->sortA.as<uint64_t>(), ix->upd_counts.as<unsigned long long>(), ix->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&got, ix->upd_counts.p, 8, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return give_back(e == hipErrorOutOfMemory ? SEBM25_E_NOMEM : SEBM25_E_HIP, std::string("update: ") + hipGetErrorString(e));
+    }
+    if (got != n_upd) return give_back(SEBM25_E_INTERNAL, "update: live row count of the update segments disagrees with their bookkeeping");
+    if ((rc = sort_and_post(one, RawRows{}, one->sortA.as<uint64_t>(), false, nullptr))) return give_back(rc, one->err);
+    uint64_t h[8];
+    if ((rc = collect_build(one, h))) return give_back(rc, one->err);
+    one->built = true;
+    drop_deltas(ix);
+    ix->deltas.push_back(one);
+    return sum_term_counts(ix);
+}
+
+int do_compact(sebm25_index* ix) {
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "compact: no index built on this handle");
+    if (ix->deltas.empty() && ix->dead_rows == 0) return SEBM25_OK;
+    int rc;
+    if ((rc = fold_deltas(ix))) return rc;   // at most one update segment from here on: sorted, no dead rows, current row format
+    const RowFmt fmt = current_fmt(ix);
+    if (fmt.tf_bits < ix->fmt.tf_bits && fmt.tf_bits < 32)
+        return fail(ix, SEBM25_E_RANGE, "compact: the grown id spaces leave too few bits for tf in the packed row (rebuild)");
+    const uint64_t n_upd = ix->deltas.empty() ? 0 : ix->deltas[0]->R;
+    const uint64_t* upd_rows = ix->deltas.empty() ? nullptr : ix->deltas[0]->sorted_rows;
+    const uint64_t total = ix->R - ix->dead_rows + n_upd;
+    if (total > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "compact: more than 2^32 - 4096 live rows");
+    if ((rc = ensure_dead_bitmaps(ix, ix))) return rc;
     // ---- merge: the base segment's rows are sorted already.  Live rows per tile, their running sum, the insertion
     // point of every update row, then one pass that writes both to their merged places.
     // The base segment's sorted rows sit in one of its two sort buffers and its posting slots in the other; the
@@ -1183,7 +1215,9 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     out->n_postings = ix->P;
     out->n_web_postings = ix->P_web;
     out->n_dead_rows = ix->dead_rows;
+    out->n_update_rows = 0;
     for (const sebm25_index* d : ix->deltas) {
+        out->n_update_rows += d->R;
         out->n_rows += d->R - d->dead_rows;
         out->n_postings += d->P;
         out->n_web_postings += d->P_web;

@@ -96,8 +96,9 @@ class SearchEngine:
             return st
 
     # ---- incremental: what changed since the last build, instead of the whole table again
-    COMPACT_SEGMENTS = 8        # fold the update segments into one beyond this many ...
-    COMPACT_DEAD_FRACTION = 0.25  # ... or when this share of the held rows is dead
+    COMPACT_UPDATE_FRACTION = 0.05  # merge the update segment into the base when it holds this share of the rows
+    #                                 (every update sorts the update segment's rows again) ...
+    COMPACT_DEAD_FRACTION = 0.25    # ... or when this share of the held rows is dead
 
     def update(self, doc_ids=(), article_urls=(), write_back: bool = True) -> dict:
         """Brings the index (and term_statistics) to the state a rebuild would give after the crawler replaced,
@@ -173,8 +174,9 @@ class SearchEngine:
                 if ex.n_articles:      # appended articles are no longer in url order: explicit ranks
                     ix.set_url_rank(SRC_NEWS, url_ranks(ex.article_urls, self._collation_key))
                 inf = ix.info() if hasattr(ix, "info") else None
-                if inf is not None and (inf.n_segments > self.COMPACT_SEGMENTS or
-                                        inf.n_dead_rows > self.COMPACT_DEAD_FRACTION * max(inf.n_rows + inf.n_dead_rows, 1)):
+                held = max(inf.n_rows + inf.n_dead_rows, 1) if inf is not None else 1
+                if inf is not None and (inf.n_update_rows > self.COMPACT_UPDATE_FRACTION * held or
+                                        inf.n_dead_rows > self.COMPACT_DEAD_FRACTION * held):
                     ix.compact()
                 st = ix.stats()
             if write_back:

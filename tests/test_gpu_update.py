@@ -140,7 +140,7 @@ def test_update_batches_equal_full_rebuild(gpu_index_factory):
         cd, ca = apply_random_batch(rng, tb, hot)
         t, u, f, m = tb.arrays(cd, ca)
         upd.update(t, u, f, m, tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=cd, changed_articles=ca)
-        assert upd.info().n_segments == batch + 2
+        assert upd.info().n_segments == 2          # the base and one update segment, however many updates
         full_build(ref, tb)
         queries = assert_same_index(upd, ref, tb, rng, hot)
     # the CPU oracle on the final table agrees with both
