@@ -1591,22 +1591,42 @@ int search_segments(sebm25_index* ix, bool news, const uint32_t* q_terms, const 
     std::vector<std::vector<uint32_t>> tmp_base(S, std::vector<uint32_t>(n_queries));
     std::vector<uint32_t> first(n_queries), nlists(n_queries);
     int rc;
-    for (size_t s = 0; s < S; ++s) {
+    // The base segment is planned first and its kernels launched; the update segments are planned while those run.
+    // An update segment is small: its queries are never cut into unit ranges, so every query has exactly one list
+    // per update segment and the places of all lists are known once the base segment is planned.
+    auto plan_first_pass = [&](size_t s, uint64_t max_tmp_entries) -> int {
         sebm25_index* seg = segs[s];
         seg->stream = ix->stream;
-        if ((rc = refresh_host_ptrs(seg)) || (plan_store_of(seg, q_offsets, n_queries, st[s]), false) ||
-            (rc = plan_pass1(seg, news, q_terms, q_offsets, n_queries, k, st[s], info[s], ~0ull))) {
+        int r;
+        if ((r = refresh_host_ptrs(seg)) || (plan_store_of(seg, q_offsets, n_queries, st[s]), false) ||
+            (r = plan_pass1(seg, news, q_terms, q_offsets, n_queries, k, st[s], info[s], max_tmp_entries))) {
             if (seg != ix) ix->err = seg->err;
-            return rc;
+            return r;
         }
-    }
+        return SEBM25_OK;
+    };
+    auto plan_and_launch = [&](size_t s) -> int {
+        sebm25_index* seg = segs[s];
+        plan_items_of(seg, info[s].n_items, st[s]);
+        int r;
+        if ((r = plan_pass2(seg, news, n_queries, st[s], info[s], tmp_base[s].data()))) {
+            if (seg != ix) ix->err = seg->err;
+            return r;
+        }
+        HIP_TRY(ix, seg->q_items.ensure((size_t)std::max(info[s].n_items, 1u) * sizeof(QItem)));
+        HIP_TRY(ix, seg->q_terms.ensure(std::max<size_t>(info[s].n_flat, 1) * 4));
+        SearchBufs b{seg->q_items.as<QItem>(), seg->q_terms.as<uint32_t>(), nullptr, nullptr,
+                     ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
+                     ix->t_score.as<double>()};
+        return score_segment(ix, seg, news, k, st[s], info[s], b, d_unit, d_score, d_mat, d_tie, d_count);
+    };
+    if ((rc = plan_first_pass(0, ~0ull))) return rc;
     uint32_t n_tmp = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
         first[q] = n_tmp;
-        for (size_t s = 0; s < S; ++s) {
-            tmp_base[s][q] = n_tmp;
-            n_tmp += st[s].q_ns[q];
-        }
+        tmp_base[0][q] = n_tmp;
+        n_tmp += st[0].q_ns[q];
+        for (size_t s = 1; s < S; ++s) tmp_base[s][q] = n_tmp++;
         nlists[q] = n_tmp - first[q];
     }
     const size_t tk = (size_t)std::max(n_tmp, 1u) * k;
@@ -1617,19 +1637,10 @@ int search_segments(sebm25_index* ix, bool news, const uint32_t* q_terms, const 
     HIP_TRY(ix, ix->t_count.ensure((size_t)std::max(n_tmp, 1u) * 4));
     HIP_TRY(ix, ix->q_first.ensure((size_t)n_queries * 4));
     HIP_TRY(ix, ix->q_n.ensure((size_t)n_queries * 4));
-    for (size_t s = 0; s < S; ++s) {
-        sebm25_index* seg = segs[s];
-        plan_items_of(seg, info[s].n_items, st[s]);
-        if ((rc = plan_pass2(seg, news, n_queries, st[s], info[s], tmp_base[s].data()))) {
-            if (seg != ix) ix->err = seg->err;
-            return rc;
-        }
-        HIP_TRY(ix, seg->q_items.ensure((size_t)std::max(info[s].n_items, 1u) * sizeof(QItem)));
-        HIP_TRY(ix, seg->q_terms.ensure(std::max<size_t>(info[s].n_flat, 1) * 4));
-        SearchBufs b{seg->q_items.as<QItem>(), seg->q_terms.as<uint32_t>(), nullptr, nullptr,
-                     ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
-                     ix->t_score.as<double>()};
-        if ((rc = score_segment(ix, seg, news, k, st[s], info[s], b, d_unit, d_score, d_mat, d_tie, d_count))) return rc;
+    if ((rc = plan_and_launch(0))) return rc;
+    for (size_t s = 1; s < S; ++s) {
+        if ((rc = plan_first_pass(s, 0))) return rc;   // 0 entries for unit-range lists: one work item per query
+        if ((rc = plan_and_launch(s))) return rc;
     }
     HIP_TRY(ix, hipMemcpyAsync(ix->q_first.p, first.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
     HIP_TRY(ix, hipMemcpyAsync(ix->q_n.p, nlists.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, ix->stream));
