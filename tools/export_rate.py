@@ -10,7 +10,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import oracle as O  # noqa: E402  (corpus generator only)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
 from search_engine_amd.store import TOKEN_COLUMNS, SqlStore  # noqa: E402
 
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000
@@ -28,7 +29,7 @@ t0 = time.perf_counter()
 step = 20_000
 total = 0
 for b in range(0, n_docs, step):
-    c = O.gen_corpus(O.make_spec(n_terms=500_000, n_docs=min(step, n_docs - b), doc_begin=b))
+    c = synth.token_rows(min(step, n_docs - b), 500_000, seed=1 + b)
     ids = (c["unit_id"].astype(np.int64) + b + 1).tolist()
     db.executemany("INSERT INTO documents(id, url, word_count) VALUES (?,?,?)",
                    [(b + i + 1, "https://s.test/%012d" % (b + i), int(w)) for i, w in enumerate(c["word_count"].tolist())])

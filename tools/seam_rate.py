@@ -12,7 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import oracle as O  # noqa: E402  (corpus generator only)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import synth  # noqa: E402
 import search_engine_amd as se  # noqa: E402
 from search_engine_amd.api import search_service as S  # noqa: E402
 from search_engine_amd.engine import SearchEngine  # noqa: E402
@@ -42,7 +43,7 @@ CREATE TABLE tokens (doc_id INTEGER, term TEXT NOT NULL, field INTEGER NOT NULL,
 CREATE TABLE term_statistics (term TEXT PRIMARY KEY, doc_frequency BIGINT NOT NULL, idf DOUBLE PRECISION NOT NULL, avg_doc_len DOUBLE PRECISION NOT NULL);
 """)
 V = 50_000
-c = O.gen_corpus(O.make_spec(n_terms=V, n_docs=n_docs))
+c = synth.token_rows(n_docs, V)
 words = [word(i) for i in range(V)]
 db.executemany("INSERT INTO documents(id, url, title, description, content, word_count) VALUES (?,?,?,?,?,?)",
                [(i + 1, "https://s.test/%09d" % i, "title %d" % i, "description of page %d" % i, "", int(w)) for i, w in enumerate(c["word_count"].tolist())])
@@ -57,7 +58,7 @@ t0 = time.perf_counter()
 eng.rebuild()
 print(f"rebuild (export + build + write-back): {time.perf_counter() - t0:.2f} s", flush=True)
 S.configure(eng)
-qs = O.gen_queries(7, V, O.zipf_cdf(V), 50, n_req, 3)
+qs = synth.queries(V, n_req, 3, 50)
 texts = [" ".join(words[int(t)] for t in q) for q in qs]
 from search_engine_amd.tokenizer import tokenize  # noqa: E402
 assert list(tokenize(texts[0]).keys()) == texts[0].split(), (texts[0], tokenize(texts[0]))
