@@ -2,6 +2,8 @@
 document's rows, app/crawler/worker.py:229-239; removed documents; new documents, articles and terms; status flips)
 the updated index must equal, bit for bit, an index built from the final table — df, row counts, N, avgdl, idf,
 doc lengths, the postings, and the top-k of both searches — and both must equal the CPU oracle on that table."""
+import os
+
 import numpy as np
 import pytest
 
@@ -173,17 +175,18 @@ def test_update_batches_equal_full_rebuild(gpu_index_factory):
     assert_same_index(upd, ref, tb, rng, hot)
 
 
-def test_update_and_compaction_cycles_reuse_segment_storage(gpu_index_factory):
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEBM25_FUZZ_UPDATE_SEEDS", "2"))))   # more for a longer sweep
+def test_update_and_compaction_cycles_reuse_segment_storage(gpu_index_factory, seed):
     """Several cycles of updates and compactions on one handle: the storage of dropped segments is used again, a
     compaction may find nothing but dead rows to drop (units removed, none added), one or many update segments to
     merge, grown term / doc id spaces (the rows are repacked); after each the index equals a full rebuild."""
-    rng = np.random.default_rng(77)
-    c = O.gen_corpus(O.make_spec(n_terms=2500, n_docs=5000, n_articles=300))   # several merge tiles of base rows
+    rng = np.random.default_rng(77 + seed)
+    c = O.gen_corpus(O.make_spec(seed=20260227 + seed, n_terms=2500, n_docs=5000, n_articles=300))   # several merge tiles of base rows
     tb = Table(c)
     hot = np.arange(10, 50)
     upd, ref = gpu_index_factory(), gpu_index_factory()
     full_build(upd, tb)
-    for cycle, n_batches in enumerate((1, 3, 0, 5, 2)):
+    for cycle, n_batches in enumerate((1, 3, 0, 5, 2) if seed == 0 else rng.integers(0, 5, 5).tolist()):
         if n_batches == 0:                              # removal only: docs and articles disappear, no rows arrive
             cd = sorted(set(rng.integers(0, tb.n_docs, 40).tolist()))
             ca = sorted(set(rng.integers(0, tb.n_articles, 10).tolist()))
