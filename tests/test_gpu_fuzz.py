@@ -10,7 +10,7 @@ import pytest
 import search_engine_amd as se
 from oracle import oracle as O
 
-from helpers import gpu_build, oracle_index, small_corpus
+from helpers import assert_build_matches, gpu_build, oracle_index, small_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,7 @@ def test_random_configurations_against_the_oracle(gpu_index_factory, case):
     orc = oracle_index(c, doc_flags=flags)
     ix = gpu_index_factory()
     gpu_build(ix, c, doc_flags=flags)
+    assert_build_matches(ix, orc)                              # df, lengths, CSR, weights: bit for bit; idf to 1e-14
     idf = orc.idf.copy()
     if case % 3 == 2:                                          # an idf table with zeros and negative values
         idf[rng.random(n_terms) < 0.2] *= -1.0
