@@ -77,6 +77,7 @@ struct sebm25_index {
     DevBuf df_sum, term_rows_sum, chg_web, chg_news, chg_coarse, upd_ids, upd_counts;
 
     std::vector<uint32_t> h_row_ptr, h_news_ptr;
+    std::vector<uint32_t> h_list_len;   // [2 V]: web and news list length of every term side by side (what the planner reads)
     bool host_ptrs_valid = false;
     SearchPlanVecs plan_vecs;    // host plan storage of sebm25_search, kept between calls
     NaHost* na_host = nullptr;   // host plan storage of sebm25_search_noalloc (pinned, fixed size)
@@ -330,9 +331,14 @@ int refresh_host_ptrs(sebm25_index* ix) {
     if (ix->host_ptrs_valid) return SEBM25_OK;
     ix->h_row_ptr.resize((size_t)ix->V + 1);
     ix->h_news_ptr.resize(ix->V);
+    ix->h_list_len.resize((size_t)ix->V * 2);
     HIP_TRY(ix, hipMemcpyAsync(ix->h_row_ptr.data(), ix->row_ptr.p, ((size_t)ix->V + 1) * 4, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(ix, hipMemcpyAsync(ix->h_news_ptr.data(), ix->news_ptr.p, (size_t)ix->V * 4, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    for (size_t t = 0; t < ix->V; ++t) {
+        ix->h_list_len[2 * t] = ix->h_news_ptr[t] - ix->h_row_ptr[t];
+        ix->h_list_len[2 * t + 1] = ix->h_row_ptr[t + 1] - ix->h_news_ptr[t];
+    }
     ix->host_ptrs_valid = true;
     return SEBM25_OK;
 }
@@ -551,6 +557,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     ix->sorted_rows = nullptr;
     ix->h_row_ptr.resize((size_t)in->n_terms + 1);  // filled by the first search; sized here so that a search never allocates them
     ix->h_news_ptr.resize(in->n_terms);
+    ix->h_list_len.resize((size_t)in->n_terms * 2);
     const uint64_t R = in->n_rows;
     const uint32_t V = in->n_terms;
     RowFmt fmt;
@@ -837,6 +844,7 @@ int fold_deltas(sebm25_index* ix) {
     one->has_dead = false; one->dead_rows = 0; one->host_ptrs_valid = false;
     one->h_row_ptr.resize((size_t)one->V + 1);
     one->h_news_ptr.resize(one->V);
+    one->h_list_len.resize((size_t)one->V * 2);
     hipError_t e = one->scalars.ensure(64);
     if (e == hipSuccess) e = hipMemsetAsync(one->scalars.p, 0, 64, ix->stream);
     if (e == hipSuccess) e = one->sortA.ensure((std::max<uint64_t>(n_upd, 1) + POST_PAD) * 8);
@@ -928,6 +936,7 @@ int do_compact(sebm25_index* ix) {
     ix->host_ptrs_valid = false;
     ix->h_row_ptr.resize((size_t)ix->V + 1);
     ix->h_news_ptr.resize(ix->V);
+    ix->h_list_len.resize((size_t)ix->V * 2);
     phases_reset(ix);
     uint64_t* scal = ix->scalars.as<uint64_t>();
     HIP_TRY(ix, hipMemsetAsync(scal, 0, 64, ix->stream));
@@ -1341,23 +1350,20 @@ size_t plan_buckets() { return (size_t)(score_fast_max_terms() + 1) * PLAN_PER_G
 int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
                uint32_t k, PlanStore& st, PlanInfo& info, uint64_t max_tmp_entries) {
     const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
-    const std::vector<uint32_t>&rp = ix->h_row_ptr, &np = ix->h_news_ptr;
-    auto list_len = [&](uint32_t t) -> uint64_t { return news ? rp[t + 1] - np[t] : np[t] - rp[t]; };
+    const uint32_t* lens = ix->h_list_len.data() + (news ? 1 : 0);
+    auto list_len = [&](uint32_t t) -> uint64_t { return lens[2 * (size_t)t]; };
     const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
     size_t nf = 0;
     uint64_t total_len = 0;
-    // the list bounds of a term are two reads at random places of two arrays of V entries: ask for those of the
-    // terms a few queries ahead while this query is planned
+    // the list length of a term is a read at a random place of an array of 2 V entries: ask for those of the terms a
+    // few queries ahead while this query is planned
     const uint64_t n_q_terms = q_offsets[n_queries];
     constexpr uint64_t AHEAD = 24;
     for (uint32_t q = 0; q < n_queries; ++q) {
         if (q_offsets[q + 1] < q_offsets[q]) return fail(ix, SEBM25_E_INVALID, "search: q_offsets must be non-decreasing");
         for (uint64_t j = q_offsets[q] + AHEAD, e = std::min(q_offsets[q + 1] + AHEAD, n_q_terms); j < e; ++j) {
             const uint32_t t = q_terms[j];
-            if (t < ix->V) {
-                __builtin_prefetch(&rp[t]);
-                __builtin_prefetch(&np[t]);
-            }
+            if (t < ix->V) __builtin_prefetch(&lens[2 * (size_t)t]);
         }
         const size_t start = nf;
         uint64_t len = 0;
@@ -1800,7 +1806,7 @@ int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms,
         return fail(ix, SEBM25_E_STATE, "search_noalloc: the index has update segments (call sebm25_compact, or use sebm25_search)");
     if (ix->device >= NA_MAX_DEVICES || !g_na_ptr[ix->device] || !ix->na_host)
         return fail(ix, SEBM25_E_STATE, "search_noalloc: the fixed storage was not set up when the handle was created");
-    if (!ix->host_ptrs_valid && (ix->h_row_ptr.size() != (size_t)ix->V + 1 || ix->h_news_ptr.size() != ix->V))
+    if (!ix->host_ptrs_valid && (ix->h_row_ptr.size() != (size_t)ix->V + 1 || ix->h_news_ptr.size() != ix->V || ix->h_list_len.size() != (size_t)ix->V * 2))
         return fail(ix, SEBM25_E_STATE, "search_noalloc: host copies of the list bounds are not reserved");
     if ((rc = refresh_host_ptrs(ix))) return rc;  // copies only: the host arrays were sized by the build
     if (!is_device_ptr(out_unit) || !is_device_ptr(out_score) || !is_device_ptr(out_matched) || !is_device_ptr(out_count) ||
