@@ -105,26 +105,40 @@ struct TopK {
         thr_score = -__builtin_huge_val();
         for (uint32_t i = lane_id(); i < S; i += 64) {
             key[i] = 0;
-            if (HAS_TIE) tie_[i] = 0xFFFFFFFFu;
+            if (HAS_TIE && !LAZY_ONLY) tie_[i] = 0xFFFFFFFFu;
             unit[i] = 0xFFFFFFFFu;
             mat[i] = 0;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    static constexpr uint32_t TIES = HAS_TIE ? (LAZY_ONLY ? S : (uint32_t)CAP) : 0u;  // tie-break keys held
+    static constexpr uint32_t TIES = (HAS_TIE && !LAZY_ONLY) ? (uint32_t)CAP : 0u;  // tie-break keys held
     static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + 1) + (size_t)TIES * 4 + 15) / 16 * 16; }
+#ifdef SEBM25_MIDF_LDS  // experiment builds only
+    static constexpr bool FILTER_MIDDLE_LISTS = true;
+#else
     static constexpr bool FILTER_MIDDLE_LISTS = false;  // measured: the lower, lazily refreshed k-th best score filters too little
-    __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? tie_[i] : unit[i]; }
+#endif
+    // LAZY_ONLY keeps no tie-break keys at all: a key is the rank of the entry's unit, read when two scores tie
+    // (and once per cut for the k-th best); a dead entry ranks behind everything
+    __device__ __forceinline__ uint32_t tie_of_unit(uint32_t u) const { return u == 0xFFFFFFFFu ? 0xFFFFFFFFu : lazy_rank[u - lazy_base]; }
+    __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? (LAZY_ONLY ? tie_of_unit(unit[i]) : tie_[i]) : unit[i]; }
 
     // one compare-exchange of the merge network: the better entry goes to slot lo
     __device__ __forceinline__ void order(uint32_t lo, uint32_t hi) {
         const uint64_t klo = key[lo], khi = key[hi];
         const uint32_t ul = unit[lo], uh = unit[hi];
-        const uint32_t tlo = HAS_TIE ? tie_[lo] : ul, thi = HAS_TIE ? tie_[hi] : uh;
+        uint32_t tlo = ul, thi = uh;
+        if (HAS_TIE && !LAZY_ONLY) {
+            tlo = tie_[lo];
+            thi = tie_[hi];
+        } else if (LAZY_ONLY && khi == klo) {
+            tlo = tie_of_unit(ul);
+            thi = tie_of_unit(uh);
+        }
         if (better(khi, thi, klo, tlo)) {
             key[lo] = khi;
             key[hi] = klo;
-            if (HAS_TIE) {
+            if (HAS_TIE && !LAZY_ONLY) {
                 tie_[lo] = thi;
                 tie_[hi] = tlo;
             }
@@ -182,10 +196,11 @@ struct TopK {
                 const uint32_t rt = HAS_TIE ? lane_xor<63>(tt) : ru;
                 const uint64_t rk = ((uint64_t)rhi << 32) | rlo;
                 const uint32_t i = S - 64u + lane;
-                if (better(rk, rt, key[i], tie(i))) {
+                const uint64_t ki = key[i];
+                if (rk > ki || (rk == ki && rt < tie(i))) {   // (the tie-break key of entry i is looked at on a tie only)
                     key[i] = rk;
                     unit[i] = ru;
-                    if (HAS_TIE) tie_[i] = rt;
+                    if (HAS_TIE && !LAZY_ONLY) tie_[i] = rt;
                     mat[i] = (unsigned char)rm;
                 }
             }
