@@ -317,7 +317,11 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     // workgroups b, b + 8, b + 16 ... run on one XCD: give them consecutive chunks, so that the runs
     // they append to a digit bin at about the same time are neighbours in that XCD's L2
     const uint32_t per_xcd = (G + 7u) / 8u;
+#ifdef SEBM25_EXP_LINEAR_CHUNKS  // experiment builds only: chunks in dispatch order (what a ticket-ordered one-sweep pass would see)
+    const uint32_t chunk = MODE == 2 ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#else
     const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#endif
     if (chunk >= G) return;
     const uint64_t tile0 = (uint64_t)chunk * SORT_TILE;
     const uint64_t end = min(R, tile0 + SORT_TILE);
