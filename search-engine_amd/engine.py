@@ -18,12 +18,13 @@ table and the idf values the job last wrote.  Here every process holds its own i
 """
 from __future__ import annotations
 
+import itertools
 import threading
 
 import numpy as np
 
 from .native import SRC_NEWS, SRC_WEB
-from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, url_ranks
+from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, UrlRanker, url_ranks
 
 
 def _pinned_alloc():
@@ -112,40 +113,62 @@ class SearchEngine:
             if getattr(self, "_doc_pos", None) is None or self._pos_of is not ex:
                 self._doc_pos = {int(d): i for i, d in enumerate(ex.doc_ids.tolist())}
                 self._art_pos = {u: i for i, u in enumerate(ex.article_urls)}
+                # ranks in url order, kept current unit by unit (a full sort of a million urls per update would
+                # cost more than everything else in it)
+                self._doc_ranker = UrlRanker(ex.doc_urls, self._collation_key, presorted=ex.url_ordered)
+                self._art_ranker = UrlRanker(ex.article_urls, self._collation_key, presorted=self._collation_key is None)
                 self._pos_of = ex
             doc_pos, art_pos = self._doc_pos, self._art_pos
             with self._lock:
                 # ---- documents: position of each changed id (new ids go to the end), columns as they are now
-                doc_ids_l = ex.doc_ids.tolist()
-                wc, fl, urls = ex.word_count.tolist(), ex.doc_flags.tolist(), ex.doc_urls
+                n_old = len(ex.doc_ids)
+                new_ids, new_wc, new_fl, new_urls = [], [], [], []
+                set_wc, set_fl, url_changes = {}, {}, {}
                 changed_docs = []
                 for d in dict.fromkeys(int(x) for x in doc_ids):
                     row = data["docs"].get(d)
                     if d not in doc_pos:
                         if row is None:
                             continue                       # never indexed and not there now
-                        doc_pos[d] = len(doc_ids_l)
-                        doc_ids_l.append(d)
-                        wc.append(0)
-                        fl.append(0)
-                        urls.append(None)
+                        doc_pos[d] = n_old + len(new_ids)
+                        new_ids.append(d)
+                        new_wc.append(0)
+                        new_fl.append(0)
+                        new_urls.append(None)
                     i = doc_pos[d]
                     changed_docs.append(i)
                     if row is None:                        # the document is gone
-                        wc[i], fl[i], urls[i] = 0, 0, None
+                        w_i, f_i, u_i = 0, 0, None
                     else:
                         url, w, status = row
-                        wc[i] = int(w or 0)
-                        fl[i] = (1 if status == "done" else 0) | (2 if w is None else 0)
-                        urls[i] = url
+                        w_i, f_i, u_i = int(w or 0), (1 if status == "done" else 0) | (2 if w is None else 0), url
+                    if i >= n_old:
+                        new_wc[i - n_old], new_fl[i - n_old], new_urls[i - n_old] = w_i, f_i, u_i
+                    else:
+                        set_wc[i], set_fl[i], url_changes[i] = w_i, f_i, u_i
+                if new_ids:
+                    ex.doc_ids = np.concatenate([ex.doc_ids, np.asarray(new_ids, np.int64)])
+                    ex.word_count = np.concatenate([ex.word_count, np.asarray(new_wc, np.uint32)])
+                    ex.doc_flags = np.concatenate([ex.doc_flags, np.asarray(new_fl, np.uint8)])
+                if set_wc:
+                    at = np.fromiter(set_wc, np.int64, len(set_wc))
+                    ex.word_count[at] = np.fromiter(set_wc.values(), np.uint32, len(set_wc))
+                    ex.doc_flags[at] = np.fromiter(set_fl.values(), np.uint8, len(set_fl))
+                for i, u in url_changes.items():
+                    ex.doc_urls[i] = u
+                ex.doc_urls.extend(new_urls)
+                self._doc_ranker.apply(url_changes, new_urls)
                 changed_arts = []
+                new_arts = []
                 for u in dict.fromkeys(article_urls):
                     if u not in art_pos:
                         if u not in data["articles"]:
                             continue
                         art_pos[u] = len(ex.article_urls)
                         ex.article_urls.append(u)
+                        new_arts.append(u)
                     changed_arts.append(art_pos[u])
+                self._art_ranker.apply({}, new_arts)
                 # ---- rows of these units, terms through the dictionary (new terms go to the end)
                 ti = ex.term_index
                 t_l, u_l, f_l, m_l = [], [], [], []
@@ -162,17 +185,16 @@ class SearchEngine:
                         f_l.append(max(int(freq), 0))
                         m_l.append(2 | ((int(fld) & 63) << 2))
                 if len(ti) > len(ex.terms):
-                    ex.terms.extend(list(ti)[len(ex.terms):])
-                ex.doc_ids = np.asarray(doc_ids_l, np.int64)
-                ex.word_count = np.asarray(wc, np.uint32)
-                ex.doc_flags = np.asarray(fl, np.uint8)
+                    ex.terms.extend(itertools.islice(ti, len(ex.terms), None))   # new terms, in the order they were given ids
                 ix.update(np.asarray(t_l, np.uint32), np.asarray(u_l, np.uint32), np.asarray(f_l, np.uint32),
                           np.asarray(m_l, np.uint8), ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count, ex.doc_flags,
                           changed_docs=changed_docs, changed_articles=changed_arts)
-                if ex.n_docs:
-                    ix.set_url_rank(SRC_WEB, url_ranks(ex.doc_urls, self._collation_key))
-                if ex.n_articles:      # appended articles are no longer in url order: explicit ranks
-                    ix.set_url_rank(SRC_NEWS, url_ranks(ex.article_urls, self._collation_key))
+                # explicit ranks only once a unit's index is no longer its place in url order (docs or articles were
+                # appended, a url changed): until then ties break on the index and searches skip the rank gather
+                if ex.n_docs and not self._doc_ranker.identity:
+                    ix.set_url_rank(SRC_WEB, self._doc_ranker.ranks())
+                if ex.n_articles and not self._art_ranker.identity:
+                    ix.set_url_rank(SRC_NEWS, self._art_ranker.ranks())
                 inf = ix.info() if hasattr(ix, "info") else None
                 held = max(inf.n_rows + inf.n_dead_rows, 1) if inf is not None else 1
                 if inf is not None and (inf.n_update_rows > self.COMPACT_UPDATE_FRACTION * held or

@@ -131,6 +131,62 @@ def _copy_unescape(strings: list) -> list:
     return [_COPY_ESCAPE_RE.sub(lambda m: _COPY_ESCAPES[m.group(0)], u) for u in strings]
 
 
+class UrlRanker:
+    """The rank of every unit in ascending url order (the tie-break key of a search), kept current while urls are
+    appended, changed or dropped, without sorting everything again: the units that changed are taken out of the
+    sorted order and put back where they belong (a binary search each), the rest keeps its place.  Same ranks as
+    `url_ranks` over the whole list; a unit without a url ranks last."""
+
+    def __init__(self, urls, key=None, presorted: bool = False):
+        self.urls = list(urls)
+        self._key = key
+        n = len(self.urls)
+        if presorted:                       # unit indices were handed out in url order
+            self.order = np.arange(n, dtype=np.int64)
+        else:
+            self.order = np.argsort(url_ranks(self.urls, key), kind="stable").astype(np.int64)
+        self.identity = presorted           # rank == unit index: the index needs no rank array
+
+    def _k(self, i):
+        u = self.urls[i]
+        return (1, "", i) if u is None else (0, u if self._key is None else self._key(u), i)
+
+    def apply(self, changed: dict, appended=()) -> bool:
+        """changed: unit index -> new url (or None); appended: urls of new units (indices follow the existing ones).
+        -> whether any rank changed."""
+        moved = [i for i, u in changed.items() if self.urls[i] != u]
+        for i in moved:
+            self.urls[i] = changed[i]
+        first_new = len(self.urls)
+        self.urls.extend(appended)
+        moved += list(range(first_new, len(self.urls)))
+        if not moved:
+            return False
+        old = np.asarray([i for i in moved if i < first_new], np.int64)
+        rest = self.order[~np.isin(self.order, old)] if len(old) else self.order
+        moved.sort(key=self._k)
+        pos = np.empty(len(moved), np.int64)
+        for j, i in enumerate(moved):       # first place in `rest` whose unit ranks behind unit i
+            k, lo, hi = self._k(i), 0, len(rest)
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if self._k(int(rest[mid])) < k:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            pos[j] = lo
+        new_order = np.insert(rest, pos, np.asarray(moved, np.int64))
+        if self.identity and not np.array_equal(new_order, np.arange(len(new_order))):
+            self.identity = False
+        self.order = new_order
+        return True
+
+    def ranks(self) -> np.ndarray:
+        rank = np.empty(len(self.order), np.uint32)
+        rank[self.order] = np.arange(len(self.order), dtype=np.uint32)
+        return rank
+
+
 def _copy_in_text(terms, df, idf, avgdl, rows_per_block: int = 1 << 16):
     """COPY text-format lines for `term_statistics`, a block of rows at a time: floats as their shortest
     round-trip decimal (the server parses them back to the same float8), text escaped as COPY expects."""

@@ -581,3 +581,35 @@ def test_intent_score_with_cached_text_features_equals_the_formula_built_from_th
                 if hits[field] == len(ctx["query_words"]):
                     want += all_bonus
         assert got == want, (q, title, desc, url)
+
+
+def test_url_ranker_keeps_the_ranks_of_a_full_sort():
+    """Units appended, urls changed or dropped: the ranks kept unit by unit equal those of sorting all urls again,
+    and `identity` holds exactly while every unit's index is its rank."""
+    import random
+
+    from search_engine_amd.store import UrlRanker, url_ranks
+
+    rnd = random.Random(1)
+    for trial in range(120):
+        n = rnd.randint(0, 40)
+        urls = list(dict.fromkeys("u%04d" % rnd.randint(0, 9999) for _ in range(n)))
+        urls = [None if rnd.random() < 0.1 else u for u in urls]
+        presorted = rnd.random() < 0.5
+        if presorted:
+            urls = [urls[i] for i in np.argsort(url_ranks(urls), kind="stable")]
+        key = (lambda u: u[::-1]) if trial % 5 == 4 and not presorted else None
+        r = UrlRanker(urls, key, presorted=presorted)
+        np.testing.assert_array_equal(r.ranks(), url_ranks(urls, key))
+        for _ in range(5):
+            changed = {rnd.randrange(len(urls)): (None if rnd.random() < 0.3 else "v%05d" % rnd.randint(0, 99999))
+                       for _ in range(rnd.randint(0, 4)) if urls}
+            appended = [None if rnd.random() < 0.1 else "w%05d" % rnd.randint(0, 99999) for _ in range(rnd.randint(0, 3))]
+            for i, u in changed.items():
+                urls[i] = u
+            urls += appended
+            r.apply(changed, appended)
+            want = url_ranks(urls, key)
+            np.testing.assert_array_equal(r.ranks(), want)
+            if r.identity:
+                np.testing.assert_array_equal(want, np.arange(len(urls)))

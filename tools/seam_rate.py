@@ -49,6 +49,8 @@ db.executemany("INSERT INTO documents(id, url, title, description, content, word
                [(i + 1, "https://s.test/%09d" % i, "title %d" % i, "description of page %d" % i, "", int(w)) for i, w in enumerate(c["word_count"].tolist())])
 db.executemany("INSERT INTO tokens VALUES (?,?,?,?,NULL,1)",
                zip((c["unit_id"].astype(np.int64) + 1).tolist(), (words[t] for t in c["term_id"].tolist()), (int(m) >> 2 for m in c["meta"].tolist()), c["tf"].tolist()))
+db.execute("CREATE INDEX idx_tokens_doc_id ON tokens(doc_id)")        # 0001_initial_schema.py:73
+db.execute("CREATE INDEX idx_tokens_article_url ON tokens(article_url)")  # 0007_unify_news_tokens.py:26
 db.commit()
 db.close()
 print(f"database: {n_docs} docs, {len(c['term_id'])} token rows", flush=True)
@@ -86,6 +88,14 @@ async def main():
     print(f"sebm25_search alone, same batches at k = 210: {n_req / dt2:.0f} queries/s", flush=True)
 
 asyncio.run(main())
+
+# the incremental path through the seam: 100 documents re-crawled (their rows read again and replaced)
+rng = np.random.default_rng(3)
+for rep in range(3):
+    ids = (rng.choice(n_docs, 100, replace=False) + 1).tolist()
+    t0 = time.perf_counter()
+    eng.update(doc_ids=ids, write_back=False)
+    print(f"SearchEngine.update of 100 docs (no write-back): {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
 
 if os.environ.get("SEAM_PROFILE"):
     import cProfile
