@@ -24,7 +24,7 @@ import threading
 import numpy as np
 
 from .native import SRC_NEWS, SRC_WEB
-from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, UrlRanker, url_ranks
+from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, UrlRanker, _factorize, url_ranks
 
 
 def _pinned_alloc():
@@ -171,19 +171,32 @@ class SearchEngine:
                 self._art_ranker.apply({}, new_arts)
                 # ---- rows of these units, terms through the dictionary (new terms go to the end)
                 ti = ex.term_index
-                t_l, u_l, f_l, m_l = [], [], [], []
-                for d, term, fld, freq in data["doc_rows"]:
-                    if int(d) in doc_pos:
-                        t_l.append(ti.setdefault(term, len(ti)))
-                        u_l.append(doc_pos[int(d)])
-                        f_l.append(max(int(freq), 0))
-                        m_l.append(1 | ((int(fld) & 63) << 2))
-                for url, term, fld, freq in data["article_rows"]:
-                    if url in art_pos and url in data["articles"]:
-                        t_l.append(ti.setdefault(term, len(ti)))
-                        u_l.append(art_pos[url])
-                        f_l.append(max(int(freq), 0))
-                        m_l.append(2 | ((int(fld) & 63) << 2))
+                parts = []
+
+                def convert(rows, unit_of, source):
+                    """(key, term, field, frequency) rows -> columns; the Python work is per distinct key and term."""
+                    if not rows:
+                        return
+                    a = np.array(rows, dtype=object)
+                    keys, kinv = _distinct(a[:, 0])
+                    pos = np.fromiter((unit_of(x) for x in keys), np.int64, len(keys))
+                    unit = pos[kinv]
+                    keep = unit >= 0
+                    if not keep.all():
+                        a, unit = a[keep], unit[keep]
+                    if not len(unit):
+                        return
+                    tcodes, tuniq = _factorize(a[:, 1])
+                    ids = np.fromiter((ti.setdefault(t, len(ti)) for t in tuniq), np.int64, len(tuniq))
+                    parts.append((ids[tcodes].astype(np.uint32), unit.astype(np.uint32),
+                                  np.maximum(a[:, 3].astype(np.int64), 0).astype(np.uint32),
+                                  (source | ((a[:, 2].astype(np.int64) & 63) << 2)).astype(np.uint8)))
+
+                convert(data["doc_rows"], lambda d: doc_pos.get(int(d), -1), 1)
+                live_arts = data["articles"]
+                convert(data["article_rows"], lambda u: art_pos.get(u, -1) if u in live_arts else -1, 2)
+                t_l, u_l, f_l, m_l = ([np.concatenate([p[i] for p in parts]) for i in range(4)] if parts else
+                                      [np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8)])
                 if len(ti) > len(ex.terms):
                     ex.terms.extend(itertools.islice(ti, len(ex.terms), None))   # new terms, in the order they were given ids
                 ix.update(np.asarray(t_l, np.uint32), np.asarray(u_l, np.uint32), np.asarray(f_l, np.uint32),
@@ -334,6 +347,12 @@ class SearchEngine:
         urls = [ex.article_urls[u] for u in unit]
         meta = self.store.news_rows(urls)
         return [meta[u] + (float(s), int(m)) for u, s, m in zip(urls, score, matched) if u in meta]
+
+
+def _distinct(values):
+    """-> (distinct values in order of first appearance, index of each value among them)."""
+    codes, uniq = _factorize(values)
+    return uniq, codes
 
 
 def _native_index(device):
