@@ -1488,15 +1488,11 @@ struct SearchBufs {  // device memory of one search call
     double* t_score;
 };
 
-// uploads one segment's plan and launches its scoring kernels; statistics, url ranks and unit bases are the
-// handle's (ix), lists and slots the segment's (seg; the handle itself is the base segment)
-int score_segment(sebm25_index* ix, const sebm25_index* seg, bool news, uint32_t k, const PlanStore& st, const PlanInfo& info,
-                  const SearchBufs& b, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie, uint32_t* d_count) {
-    phase_begin(ix, "search_plan_h2d");
-    HIP_TRY(ix, hipMemcpyAsync(b.items, st.items, (size_t)info.n_items * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
-    if (info.n_flat)
-        HIP_TRY(ix, hipMemcpyAsync(b.terms, st.flat, (size_t)info.n_flat * 4, hipMemcpyHostToDevice, ix->stream));
-    phase_end(ix);
+// kernel arguments of one segment's scoring launch: statistics, url ranks and unit bases are the handle's (ix), lists and
+// slots the segment's (seg; the handle itself is the base segment)
+ScoreArgs score_args_of(const sebm25_index* ix, const sebm25_index* seg, bool news, uint32_t k, const PlanInfo& info,
+                        const SearchBufs& b, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie,
+                        uint32_t* d_count) {
     ScoreArgs a{};
     a.row_ptr = seg->row_ptr.as<uint32_t>();
     a.news_ptr = seg->news_ptr.as<uint32_t>();
@@ -1513,6 +1509,19 @@ int score_segment(sebm25_index* ix, const sebm25_index* seg, bool news, uint32_t
     a.k = k;
     a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
     a.tmp_unit = b.t_unit; a.tmp_score = b.t_score; a.tmp_matched = b.t_mat; a.tmp_tie = b.t_tie; a.tmp_count = b.t_count;
+    return a;
+}
+
+// uploads one segment's plan and launches its scoring kernels; statistics, url ranks and unit bases are the
+// handle's (ix), lists and slots the segment's (seg; the handle itself is the base segment)
+int score_segment(sebm25_index* ix, const sebm25_index* seg, bool news, uint32_t k, const PlanStore& st, const PlanInfo& info,
+                  const SearchBufs& b, uint32_t* d_unit, double* d_score, uint32_t* d_mat, uint32_t* d_tie, uint32_t* d_count) {
+    phase_begin(ix, "search_plan_h2d");
+    HIP_TRY(ix, hipMemcpyAsync(b.items, st.items, (size_t)info.n_items * sizeof(QItem), hipMemcpyHostToDevice, ix->stream));
+    if (info.n_flat)
+        HIP_TRY(ix, hipMemcpyAsync(b.terms, st.flat, (size_t)info.n_flat * 4, hipMemcpyHostToDevice, ix->stream));
+    phase_end(ix);
+    const ScoreArgs a = score_args_of(ix, seg, news, k, info, b, d_unit, d_score, d_mat, d_tie, d_count);
     phase_begin(ix, "score_topk");
     launch_score(a, info.n_by_t, ix->stream);
     phase_end(ix);
@@ -1533,22 +1542,7 @@ int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, cons
     }
     phase_end(ix);
 
-    ScoreArgs a{};
-    a.row_ptr = ix->row_ptr.as<uint32_t>();
-    a.news_ptr = ix->news_ptr.as<uint32_t>();
-    a.post_unit = ix->post_unit;
-    a.post_w = ix->post_w;
-    a.idf_used = ix->idf_used.as<double>();
-    a.url_rank = news ? (ix->has_rank_news ? ix->url_rank_news.as<uint32_t>() : nullptr)
-                      : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);
-    a.unit_base = news ? ix->news_base : ix->web_base;
-    a.news = news ? 1 : 0;
-    a.items = b.items;
-    a.q_terms = b.terms;
-    a.n_items = info.n_items;
-    a.k = k;
-    a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
-    a.tmp_unit = b.t_unit; a.tmp_score = b.t_score; a.tmp_matched = b.t_mat; a.tmp_tie = b.t_tie; a.tmp_count = b.t_count;
+    const ScoreArgs a = score_args_of(ix, ix, news, k, info, b, d_unit, d_score, d_mat, d_tie, d_count);
     phase_begin(ix, "score_topk");
     launch_score(a, info.n_by_t, ix->stream);
     phase_end(ix);
