@@ -645,9 +645,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         all_positive = all_positive && idf_p[t] > 0.0 && idf_p[t] < 1e300;
         inv_idf_p[t] = 1.0 / idf_p[t];
     }
-    constexpr bool MIDF = T > 2 && TK::FILTER_MIDDLE_LISTS;
+    constexpr bool MIDF = T >= 2 && TK::FILTER_MIDDLE_LISTS;
+    // the first list that is filtered: with two lists the shorter one (every insert of such a query is its own: 10M-doc
+    // index, 10k two-term queries at k = 10: 10.9 -> 8.9 ms); with more lists the second, because filtering the
+    // shortest as well needs the block maximum of the second list at every step and wins too little back (17.6 -> 18.1 ms)
+    constexpr int FIRST_F = T == 2 ? 0 : 1;
     uint32_t maxw[T];       // largest weight in the list's current block
-    uint32_t w_mid[T];      // lists 1 .. T-2: smallest weight whose posting is inserted when no shorter list holds the unit
+    uint32_t w_mid[T];      // lists FIRST_F .. T-2: smallest weight whose posting is inserted when no shorter list holds the unit
 #pragma unroll
     for (int t = 0; t < T; ++t) w_mid[t] = 0;
     auto block_max = [&](int t) {
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #pragma unroll
         for (int j = 0; j < BM; ++j)
             if (j < nb(t)) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
-        if (MIDF && t >= 2) block_max(t);
+        if (MIDF && t > FIRST_F) block_max(t);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         const uint32_t Fc = min(F, INF - 1u);
         F_prev = Fc;
 
-        // Lists between the shortest and the longest: a posting whose unit no shorter list delivered is inserted only
+        // Lists FIRST_F .. T-2: a posting whose unit no shorter list delivered is inserted only
         // if its own part plus the most the longer lists can add (idf x the largest weight of their current blocks,
         // which hold every posting of this step) reaches the k-th best score.  A unit dropped here scores below that
         // score whatever the longer lists hold for it, and whatever part of it a longer list may still offer is
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             if (all_positive && thr > 0.0) {
                 double ub = 0.0;
 #pragma unroll
-                for (int t = T - 2; t >= 1; --t) {
+                for (int t = T - 2; t >= FIRST_F; --t) {
                     ub += idf_p[t + 1] * (double)maxw[t + 1];
                     const double x = (thr * (1.0 - 1e-12) - ub) * inv_idf_p[t];
                     w_mid[t] = x < 2.0 ? 0u : (x >= 65536.0 ? 0xFFFFu : (uint32_t)x - 1u);
@@ -784,6 +788,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         __builtin_amdgcn_wave_barrier();
                     }
                     if (t < T - 1) s = s && !found && w[t][j] >= w_mid[t];  // what is left goes into the table below
+                } else if (MIDF && FIRST_F == 0) {
+                    s = s && w[t][j] >= w_mid[t];  // the shortest list: nothing to look up, the same bound
                 }
                 if (t == T - 1) {
                     // a unit that only the longest list holds has its final score already: straight to the candidates
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #pragma unroll
                 for (int j = 0; j < BM; ++j)
                     if (j < nb(t)) clast[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)u[t][j], 63);
-                if (MIDF && t >= 2) block_max(t);
+                if (MIDF && t > FIRST_F) block_max(t);
             }
         }
 #ifdef SEBM25_EXP_STATS
