@@ -133,11 +133,11 @@ class ShardedIndex:
                 gathered.copy_(g_host)
             else:
                 dist.all_gather_into_tensor(gathered, mine, group=self.group)    # per-shard top-k lists, one collective
-                # the collective is only ordered against torch's current stream; the merge below runs on the library's
-                # stream, which may be another one: wait here until the lists have arrived
-                if self.device.type == "cuda":
-                    torch.cuda.current_stream(self.device).synchronize()
             g = self._views(gathered, nq, k, lists=self.world)
+            # the collective and the list-major copies made above are only ordered against torch's current stream; the
+            # merge below runs on the library's stream, which may be another one: wait here until the lists are in place
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
             res = dict(unit=torch.empty_like(loc["unit"]), score=torch.empty_like(loc["score"]),
                        matched=torch.empty_like(loc["matched"]), tie=torch.empty_like(loc["tie"]),
                        count=torch.empty_like(loc["count"]))
