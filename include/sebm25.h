@@ -102,7 +102,9 @@ int sebm25_create(int device, sebm25_index** out);
 void sebm25_destroy(sebm25_index* ix);
 const char* sebm25_last_error(const sebm25_index* ix);
 /* All work of this handle is enqueued on `hip_stream` (a hipStream_t; NULL = the default
- * stream, which is also PyTorch's default on ROCm). */
+ * stream, which is also PyTorch's default on ROCm).  Every call returns after its work on that
+ * stream has finished, so its outputs may be read from any stream.  Device arrays passed IN are
+ * read on that stream: a caller that fills them on another stream waits for that stream first. */
 int sebm25_set_stream(sebm25_index* ix, void* hip_stream);
 
 /* ---- index build: replaces app/batch/bm25_stats.py:9-27 ---------------------------------- */
