@@ -121,7 +121,11 @@ class _MicroBatcher:
                         fut.set_exception(e)
             else:
                 for (*_, fut), res in zip(batch, results):
-                    if not fut.done():
+                    if fut.done():
+                        continue
+                    if isinstance(res, Exception):    # this request alone cannot be scored
+                        fut.set_exception(res)
+                    else:
                         fut.set_result(res)
 
 

@@ -23,7 +23,7 @@ import threading
 
 import numpy as np
 
-from .native import SRC_NEWS, SRC_WEB
+from .native import MAX_QUERY_TERMS, SRC_NEWS, SRC_WEB
 from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, UrlRanker, _factorize, url_ranks
 
 
@@ -284,11 +284,15 @@ class SearchEngine:
         self.ensure_ready()
         with self._lock:
             ex, ix = self.export, self.index
-            queries = [[ex.term_index[t] for t in terms if t in ex.term_index] for terms, _ in requests]
+            queries = [list(dict.fromkeys(ex.term_index[t] for t in terms if t in ex.term_index)) for terms, _ in requests]
             kmax = max([int(limit) for _, limit in requests] + [1])
-            live = [i for i, q in enumerate(queries) if q]      # unknown terms match nothing
+            # unknown terms match nothing; a query beyond the library's limit fails alone, not the batch it came in
+            live = [i for i, q in enumerate(queries) if q and len(q) <= MAX_QUERY_TERMS]
             out = ix.search([queries[i] for i in live], kmax, source=source) if live else None
         res = [(np.zeros(0, np.uint32), np.zeros(0), np.zeros(0, np.uint32))] * len(requests)
+        for i, q in enumerate(queries):
+            if len(q) > MAX_QUERY_TERMS:
+                res[i] = ValueError(f"query with {len(q)} distinct indexed terms: at most {MAX_QUERY_TERMS} are scored")
         for j, i in enumerate(live):
             # a result list cut at a smaller limit is a prefix of the list cut at a larger one
             n = min(int(out["count"][j]), int(requests[i][1]))
@@ -297,19 +301,28 @@ class SearchEngine:
 
     def _score(self, source: int, terms, limit: int):
         ex, res = self._score_many(source, [(terms, limit)])
+        if isinstance(res[0], Exception):
+            raise res[0]
         return (ex,) + res[0]
 
     def score_batch(self, requests) -> list:
         """requests: [(kind, terms, limit)], kind 'web' | 'news'.  One batched GPU search per kind and one
         metadata statement per kind for the whole batch.  -> per request ('rows', rows) in the layout of
         score_web / score_news, or ('pairs', [(token_score, matched_terms)]) for web requests when the row
-        text cannot be decoded (the reference's fallback, search_service.py:321-338)."""
+        text cannot be decoded (the reference's fallback, search_service.py:321-338), or the exception of a
+        request that cannot be scored (more distinct terms than the library takes)."""
         out = [None] * len(requests)
         for kind, source in (("web", SRC_WEB), ("news", SRC_NEWS)):
             idx = [i for i, r in enumerate(requests) if r[0] == kind]
             if not idx:
                 continue
             ex, res = self._score_many(source, [(requests[i][1], requests[i][2]) for i in idx])
+            failed = [(i, r) for i, r in zip(idx, res) if isinstance(r, Exception)]
+            if failed:      # these requests get their exception, the others their rows
+                for i, r in failed:
+                    out[i] = r
+                keep = [j for j, r in enumerate(res) if not isinstance(r, Exception)]
+                idx, res = [idx[j] for j in keep], [res[j] for j in keep]
             if kind == "web":
                 ids = [[int(ex.doc_ids[u]) for u in unit] for unit, _, _ in res]
                 try:

@@ -245,6 +245,30 @@ def test_fallback_rows_and_concurrent_requests_on_cpu_stand_in(tmp_path):
     check_concurrent_requests(engine)
 
 
+def test_a_query_beyond_the_term_limit_fails_alone(tmp_path, monkeypatch):
+    """A request with more distinct indexed terms than the library scores gets an exception of its own; the requests
+    that were batched with it get their results (the reference's `= ANY($1)` has no such limit, so this is where the
+    drop-in says no instead of failing a whole batch)."""
+    import search_engine_amd.engine as engine_module
+
+    engine = run_flow(tmp_path, OracleBackedIndex)
+    svc = ss.SearchService(engine)
+    alone = asyncio.run(svc.perform_web_search(q="radix sort", limit=5))
+    monkeypatch.setattr(engine_module, "MAX_QUERY_TERMS", 2)
+
+    async def together():
+        return await asyncio.gather(svc.perform_web_search(q="postgres sorting rows", limit=5),
+                                    svc.perform_web_search(q="radix sort", limit=5), return_exceptions=True)
+
+    before = svc.batcher.batches
+    long_one, short_one = asyncio.run(together())
+    assert svc.batcher.batches - before == 1
+    assert isinstance(long_one, ValueError) and "distinct indexed terms" in str(long_one)
+    assert short_one.model_dump() == alone.model_dump()
+    with pytest.raises(ValueError):
+        engine.score_web(list(tokenize("postgres sorting rows").keys()), 10)
+
+
 def test_job_and_service_in_separate_engines(tmp_path):
     """The statistics job and the search API are separate processes in the reference (docker-compose.yml:50,67):
     here two engines over one database.  The service builds itself on first use, scores with the table's idf
