@@ -207,6 +207,9 @@ typedef struct sebm25_index_info {
     uint32_t n_segments;      /* 1, or 2 while an update segment is held (since the last build or compaction) */
     uint64_t n_dead_rows;     /* rows of replaced or removed units that the segments still carry */
     uint64_t n_update_rows;   /* rows of the update segment: every update sorts them again, so compact before they are many */
+    uint32_t fused_postings;  /* 1: the base segment's posting slots were written by the last sort pass (unit-major rows,
+                                 1025 .. 2^20 terms, no run the pass leaves to the separate posting pass); 0: by the
+                                 posting pass over the sorted rows.  The results are the same. */
 } sebm25_index_info;
 int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out);
 

@@ -53,7 +53,7 @@ struct sebm25_index {
     uint64_t N = 1;
     double avgdl = 0.0;
 
-    DevBuf sortA, sortB, chunk_hist, group_off, bin_start, scan_tmp;
+    DevBuf sortA, sortB, chunk_hist, group_off, bin_start, scan_tmp;  // bin_start: one array per pass parity
     DevBuf row_ptr, news_ptr, df_local, df_global, term_rows, idf, idf_used, doc_len;
     DevBuf scalars;  // u64[8]: 0 kept postings, 1 web heads, 2 n_done, 3 n_wc, 4 sum_wc, 5 kept web postings; u32 err at [7]
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
@@ -62,6 +62,14 @@ struct sebm25_index {
     uint32_t* post_unit = nullptr;
     uint32_t* post_w = nullptr;  // weights in tenths
     const uint64_t* sorted_rows = nullptr;  // the sorted packed rows this segment was built from (read again by updates)
+    // A build whose last sort pass wrote the posting slots has no sorted rows: the input of that pass (the
+    // rows ordered by the earlier digits) is kept with the pass's offsets, and the rows are sorted out of it
+    // when an update, a compaction or the exact second look at unusual runs first asks for them.
+    const uint64_t* unsorted_rows = nullptr;
+    int last_shift = 0, last_bits = 0;
+    bool keep_rows = false;   // this segment's sorted rows are wanted right away (update segments)
+    bool fused = true;        // SEBM25_FUSED_POSTINGS=0: always the separate posting pass
+    bool built_fused = false; // the slots this segment holds were written by the last sort pass
     const uint32_t* wc_dev = nullptr;       // device views of the last build's word_count / doc_flags arrays
     const uint8_t* flags_dev = nullptr;
 
@@ -373,6 +381,8 @@ sebm25_index* take_segment(sebm25_index* ix) {
         seg->device = ix->device;
         seg->stream = ix->stream;
         seg->sort_bits = ix->sort_bits;
+        seg->fused = ix->fused;
+        seg->keep_rows = true;  // read again at once: rows of unlisted units, the fold with the next update's rows
     }
     return seg;
 }
@@ -399,6 +409,67 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
     return SEBM25_OK;
 }
 
+// The separate posting pass over sorted rows: slots into `slots` (the sort buffer that does not hold the rows), list
+// bounds, df and row counts.  Counters in ix->scalars [0], [1], [5] and the per-term arrays are (re)initialised here.
+int post_sorted(sebm25_index* ix, const uint64_t* sorted, uint64_t* slots) {
+    const uint64_t R = ix->R;
+    const uint32_t V = ix->V;
+    const size_t Rcap = std::max<uint64_t>(R, 1);
+    uint64_t* scal = ix->scalars.as<uint64_t>();
+    uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
+    uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
+    uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
+    ix->post_unit = reinterpret_cast<uint32_t*>(slots);
+    ix->post_w = reinterpret_cast<uint32_t*>(slots) + Rcap + POST_PAD;
+    ix->built_fused = false;
+    // one contiguous range of rows per wavefront
+    uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
+    chunk2 = (chunk2 + RED_BATCH - 1) / RED_BATCH * RED_BATCH;
+    const uint32_t n_chunks = (uint32_t)((R + chunk2 - 1) / chunk2);
+    HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(row_ptr, 0xFF, ((size_t)V + 1) * 4, ix->stream));
+    HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
+    HIP_TRY(ix, ix->scan_tmp.ensure(std::max(row_ptr_fill_tmp_words(V), postings_tmp_words(n_chunks)) * 4));
+    phase_begin(ix, "postings");
+    launch_postings(sorted, R, chunk2, n_chunks, ix->fmt, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
+                    ix->df_local.as<uint32_t>(), scal, ix->scan_tmp.as<uint32_t>(), err_dev, ix->stream);
+    phase_end(ix);
+    phase_begin(ix, "term_stats");
+    launch_row_ptr_fill(row_ptr, V, R, ix->scan_tmp.as<uint32_t>(), ix->stream);
+    launch_term_stats(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->stream);
+    phase_end(ix);
+    HIP_TRY(ix, hipGetLastError());
+    return SEBM25_OK;
+}
+
+// Sorted rows of a segment whose last sort pass wrote posting slots instead: that pass again, this time writing the
+// rows, from its kept input and offsets into a buffer that then replaces the input's.
+int ensure_sorted_rows(sebm25_index* ix, sebm25_index* seg) {
+    if (seg->sorted_rows || seg->R == 0 || !seg->unsorted_rows) return SEBM25_OK;
+    const size_t Rcap = std::max<uint64_t>(seg->R, 1);
+    DevBuf out;
+    HIP_TRY(ix, out.ensure((Rcap + POST_PAD) * 8));
+    BuildCtx ctx{};
+    ctx.fmt = seg->fmt;
+    ctx.n_terms = seg->V; ctx.n_docs = seg->n_docs; ctx.n_articles = seg->n_articles;
+    ctx.err = reinterpret_cast<uint32_t*>(seg->scalars.as<uint64_t>() + 7);
+    const uint32_t G = (uint32_t)((seg->R + SORT_TILE - 1) / SORT_TILE);
+    launch_sort_scatter(2, RawRows{}, seg->unsorted_rows, out.as<uint64_t>(), seg->R, G, seg->last_shift, seg->last_bits, ctx,
+                        seg->chunk_hist.as<unsigned short>(), seg->group_off.as<uint32_t>(), ix->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+        out.release();
+        HIP_TRY(ix, e);
+    }
+    DevBuf& in_buf = seg->unsorted_rows == seg->sortA.as<uint64_t>() ? seg->sortA : seg->sortB;
+    in_buf.release();
+    in_buf = out;
+    seg->sorted_rows = in_buf.as<uint64_t>();
+    seg->unsorted_rows = nullptr;
+    return SEBM25_OK;
+}
+
 // Sorts the rows of a segment and writes its posting slots, list bounds, df and row counts.  The rows are the
 // caller's raw arrays (start_packed == nullptr) or packed rows that already sit in sort buffer A (compaction).
 // ix->R / V / fmt / n_docs / n_articles describe the segment; buffers are sized here.
@@ -420,7 +491,8 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
     uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
     uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
     uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
-    const uint64_t* sorted_rows = nullptr;
+    ix->sorted_rows = nullptr;
+    ix->unsorted_rows = nullptr;
 
     if (R == 0) {
         HIP_TRY(ix, hipMemsetAsync(row_ptr, 0, ((size_t)V + 1) * 4, ix->stream));
@@ -430,87 +502,97 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
         ix->post_unit = ix->sortA.as<uint32_t>();
         ix->post_w = ix->sortA.as<uint32_t>() + 1;
         ix->n_pass = 0;
-    } else {
-        // ---- stable LSD radix sort on the key bits of the packed row
-        const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
-        const int key_bits = 64 - key_lo;
-        const int n_pass = presorted ? 0 : (key_bits + ix->sort_bits - 1) / ix->sort_bits;
-        ix->n_pass = (uint32_t)n_pass;
-        // one chunk = one tile = the work of one scatter workgroup
-        const uint64_t chunk_rows = SORT_TILE;
-        const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
-        const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
-        HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 2));
-        HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
-        HIP_TRY(ix, ix->bin_start.ensure((size_t)SORT_MAX_BINS * 4));
-        HIP_TRY(ix, ix->scan_tmp.ensure(sort_offsets_tmp_words() * 4));
-
-        BuildCtx ctx{};
-        ctx.fmt = fmt;
-        ctx.n_terms = V; ctx.n_docs = ix->n_docs; ctx.n_articles = ix->n_articles;
-        ctx.check_order = unit_major ? 1u : 0u;
-        ctx.doc_len = ix->doc_len.as<uint32_t>();
-        ctx.doc_flags = ix->n_docs ? flags_dev : nullptr;
-        ctx.err = err_dev;
-
-        // at most ceil(54 key bits / 4-bit digits) = 14 passes
-        static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6", "sort_hist_7",
-                                           "sort_hist_8", "sort_hist_9", "sort_hist_10", "sort_hist_11", "sort_hist_12", "sort_hist_13", "sort_hist_14", "sort_hist_15"};
-        static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6", "sort_scan_7",
-                                           "sort_scan_8", "sort_scan_9", "sort_scan_10", "sort_scan_11", "sort_scan_12", "sort_scan_13", "sort_scan_14", "sort_scan_15"};
-        static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6", "sort_scatter_7",
-                                           "sort_scatter_8", "sort_scatter_9", "sort_scatter_10", "sort_scatter_11", "sort_scatter_12", "sort_scatter_13", "sort_scatter_14", "sort_scatter_15"};
-        if (n_pass > 16) return fail(ix, SEBM25_E_INTERNAL, "build: more than 16 sort passes");
-        const uint64_t* src_packed = start_packed;
-        uint64_t* bufs[2] = {ix->sortA.as<uint64_t>(), ix->sortB.as<uint64_t>()};
-        const int first_dst = start_packed ? 1 : 0;  // packed rows start in buffer A: the first pass writes B
-        int shift = key_lo;
-        for (int p = 0; p < n_pass; ++p) {
-            const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
-            const int mode = (p == 0 && !start_packed) ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
-            uint64_t* dst = bufs[(p + first_dst) & 1];
-            unsigned short* prefix = ix->chunk_hist.as<unsigned short>();
-            uint32_t* group_off = ix->group_off.as<uint32_t>();
-            uint32_t* bin_start = ix->bin_start.as<uint32_t>();
-            phase_begin(ix, hist_names[p]);
-            launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, ix->stream);
-            phase_end(ix);
-            phase_begin(ix, scan_names[p]);
-            launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->scan_tmp.as<uint32_t>(), ix->stream);
-            phase_end(ix);
-            phase_begin(ix, scat_names[p]);
-            launch_sort_scatter(mode, raw, src_packed, dst, R, G, shift, bits, ctx, prefix, group_off, ix->stream);
-            phase_end(ix);
-            src_packed = dst;
-            shift += bits;
-        }
-        HIP_TRY(ix, hipGetLastError());
-        const uint64_t* sorted = src_packed;
-        sorted_rows = sorted;
-        uint64_t* other = sorted == bufs[0] ? bufs[1] : bufs[0];  // the buffer the last pass did not write
-        // postings live in the free sort buffer: unit ids in its first half, weights in the second
-        ix->post_unit = reinterpret_cast<uint32_t*>(other);
-        ix->post_w = reinterpret_cast<uint32_t*>(other) + Rcap + POST_PAD;
-
-        // ---- postings, one slot per sorted row: one contiguous range of rows per wavefront
-        uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
-        chunk2 = (chunk2 + RED_BATCH - 1) / RED_BATCH * RED_BATCH;
-        const uint32_t n_chunks = (uint32_t)((R + chunk2 - 1) / chunk2);
-        HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
-        HIP_TRY(ix, hipMemsetAsync(row_ptr, 0xFF, ((size_t)V + 1) * 4, ix->stream));
-        HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
-        HIP_TRY(ix, ix->scan_tmp.ensure(std::max(row_ptr_fill_tmp_words(V), postings_tmp_words(n_chunks)) * 4));
-        phase_begin(ix, "postings");
-        launch_postings(sorted, R, chunk2, n_chunks, fmt, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
-                        ix->df_local.as<uint32_t>(), scal, ix->scan_tmp.as<uint32_t>(), err_dev, ix->stream);
-        phase_end(ix);
-        phase_begin(ix, "term_stats");
-        launch_row_ptr_fill(row_ptr, V, R, ix->scan_tmp.as<uint32_t>(), ix->stream);
-        launch_term_stats(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->stream);
-        phase_end(ix);
+        ix->built_fused = false;
+        return SEBM25_OK;
     }
-    ix->sorted_rows = sorted_rows;
+    // ---- stable LSD radix sort on the key bits of the packed row
+    const int key_lo = unit_major ? fmt.term_shift() : fmt.key_shift();
+    const int key_bits = 64 - key_lo;
+    const int n_pass = presorted ? 0 : (key_bits + ix->sort_bits - 1) / ix->sort_bits;
+    ix->n_pass = (uint32_t)n_pass;
+    // one chunk = one tile = the work of one scatter workgroup
+    const uint64_t chunk_rows = SORT_TILE;
+    const uint32_t G = (uint32_t)((R + chunk_rows - 1) / chunk_rows);
+    const uint32_t n_groups = (G + SORT_GROUP - 1) / SORT_GROUP;
+    HIP_TRY(ix, ix->chunk_hist.ensure((size_t)SORT_MAX_BINS * G * 2));
+    HIP_TRY(ix, ix->group_off.ensure((size_t)SORT_MAX_BINS * n_groups * 4));
+    HIP_TRY(ix, ix->bin_start.ensure((size_t)SORT_MAX_BINS * 4 * 2));
+    HIP_TRY(ix, ix->scan_tmp.ensure(std::max(sort_offsets_tmp_words(), scatter_post_tmp_words(G)) * 4));
+    // Two passes over the term bits of unit-major raw rows (every vocabulary of 1025 .. 2^20 terms): the second
+    // pass writes the posting slots itself and the sorted rows are never stored.
+    const bool fuse = ix->fused && !ix->keep_rows && !start_packed && !presorted && unit_major && n_pass == 2;
+
+    BuildCtx ctx{};
+    ctx.fmt = fmt;
+    ctx.n_terms = V; ctx.n_docs = ix->n_docs; ctx.n_articles = ix->n_articles;
+    ctx.check_order = unit_major ? 1u : 0u;
+    ctx.doc_len = ix->doc_len.as<uint32_t>();
+    ctx.doc_flags = ix->n_docs ? flags_dev : nullptr;
+    ctx.err = err_dev;
+
+    // at most ceil(54 key bits / 4-bit digits) = 14 passes
+    static const char* hist_names[] = {"sort_hist_0", "sort_hist_1", "sort_hist_2", "sort_hist_3", "sort_hist_4", "sort_hist_5", "sort_hist_6", "sort_hist_7",
+                                       "sort_hist_8", "sort_hist_9", "sort_hist_10", "sort_hist_11", "sort_hist_12", "sort_hist_13", "sort_hist_14", "sort_hist_15"};
+    static const char* scan_names[] = {"sort_scan_0", "sort_scan_1", "sort_scan_2", "sort_scan_3", "sort_scan_4", "sort_scan_5", "sort_scan_6", "sort_scan_7",
+                                       "sort_scan_8", "sort_scan_9", "sort_scan_10", "sort_scan_11", "sort_scan_12", "sort_scan_13", "sort_scan_14", "sort_scan_15"};
+    static const char* scat_names[] = {"sort_scatter_0", "sort_scatter_1", "sort_scatter_2", "sort_scatter_3", "sort_scatter_4", "sort_scatter_5", "sort_scatter_6", "sort_scatter_7",
+                                       "sort_scatter_8", "sort_scatter_9", "sort_scatter_10", "sort_scatter_11", "sort_scatter_12", "sort_scatter_13", "sort_scatter_14", "sort_scatter_15"};
+    if (n_pass > 16) return fail(ix, SEBM25_E_INTERNAL, "build: more than 16 sort passes");
+    const uint64_t* src_packed = start_packed;
+    uint64_t* bufs[2] = {ix->sortA.as<uint64_t>(), ix->sortB.as<uint64_t>()};
+    const int first_dst = start_packed ? 1 : 0;  // packed rows start in buffer A: the first pass writes B
+    int shift = key_lo, bits_before = 0;
+    for (int p = 0; p < n_pass; ++p) {
+        const int bits = key_bits / n_pass + (p < key_bits % n_pass ? 1 : 0);
+        const int mode = (p == 0 && !start_packed) ? (shift >= fmt.term_shift() ? 0 : 1) : 2;
+        uint64_t* dst = bufs[(p + first_dst) & 1];
+        unsigned short* prefix = ix->chunk_hist.as<unsigned short>();
+        uint32_t* group_off = ix->group_off.as<uint32_t>();
+        uint32_t* bin_start = ix->bin_start.as<uint32_t>() + (size_t)(p & 1) * SORT_MAX_BINS;
+        phase_begin(ix, hist_names[p]);
+        launch_sort_hist(mode, raw, src_packed, R, chunk_rows, G, shift, bits, ctx, prefix, group_off, ix->stream);
+        phase_end(ix);
+        phase_begin(ix, scan_names[p]);
+        launch_sort_offsets(group_off, n_groups, bits, bin_start, ix->scan_tmp.as<uint32_t>(), ix->stream);
+        phase_end(ix);
+        if (fuse && p == 1) {
+            // the posting slots take the place the sorted rows would have had
+            ix->post_unit = reinterpret_cast<uint32_t*>(dst);
+            ix->post_w = reinterpret_cast<uint32_t*>(dst) + Rcap + POST_PAD;
+            HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
+            HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
+            HIP_TRY(ix, hipMemsetAsync(ix->post_unit + R, 0, (size_t)POST_PAD * 4, ix->stream));   // what lies behind the last slot
+            HIP_TRY(ix, hipMemsetAsync(ix->post_w + R, 0xFF, (size_t)POST_PAD * 4, ix->stream));   // reads as holes
+            phase_begin(ix, "scatter_postings");
+            launch_sort_scatter_post(src_packed, R, G, shift, bits, ctx, prefix, group_off, ix->post_unit, ix->post_w, news_ptr,
+                                     ix->df_local.as<uint32_t>(), ix->scan_tmp.as<uint32_t>(), scal, ix->stream);
+            phase_end(ix);
+            phase_begin(ix, "term_stats");
+            launch_first_slots(src_packed, R, G, shift, bits_before, bits, ix->bin_start.as<uint32_t>(), prefix, group_off, bin_start,
+                               V, row_ptr, ix->stream);
+            launch_term_stats_dup(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->df_local.as<uint32_t>(), ix->stream);
+            phase_end(ix);
+            HIP_TRY(ix, hipGetLastError());
+            ix->unsorted_rows = src_packed;
+            ix->built_fused = true;
+            ix->last_shift = shift;
+            ix->last_bits = bits;
+            return SEBM25_OK;
+        }
+        phase_begin(ix, scat_names[p]);
+        launch_sort_scatter(mode, raw, src_packed, dst, R, G, shift, bits, ctx, prefix, group_off, ix->stream);
+        phase_end(ix);
+        src_packed = dst;
+        shift += bits;
+        bits_before = bits;
+    }
     HIP_TRY(ix, hipGetLastError());
+    const uint64_t* sorted = src_packed;
+    uint64_t* other = sorted == bufs[0] ? bufs[1] : bufs[0];  // the buffer the last pass did not write
+    // postings live in the free sort buffer: unit ids in its first half, weights in the second
+    int rc = post_sorted(ix, sorted, other);
+    if (rc) return rc;
+    ix->sorted_rows = sorted;
     return SEBM25_OK;
 }
 
@@ -521,6 +603,20 @@ int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
     HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     uint32_t dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    if ((dev_err & DEV_NEED_FIXUP) && !(dev_err & (DEV_ERR_RANGE | DEV_ERR_ORDER)) && ix->unsorted_rows) {
+        // the last sort pass met runs it does not turn into slots itself (see post_tile): the rows are sorted out
+        // and the separate posting pass redoes slots, list bounds and counts
+        int rc = ensure_sorted_rows(ix, ix);
+        if (rc) return rc;
+        HIP_TRY(ix, hipMemsetAsync(scal, 0, 16, ix->stream));       // kept postings, web heads
+        HIP_TRY(ix, hipMemsetAsync(scal + 5, 0, 8, ix->stream));    // kept web postings
+        HIP_TRY(ix, hipMemsetAsync(scal + 7, 0, 8, ix->stream));    // device error word
+        uint64_t* slots = ix->sorted_rows == ix->sortA.as<uint64_t>() ? ix->sortB.as<uint64_t>() : ix->sortA.as<uint64_t>();
+        if ((rc = post_sorted(ix, ix->sorted_rows, slots))) return rc;
+        HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+        dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
+    }
     if ((dev_err & DEV_NEED_FIXUP) && !(dev_err & (DEV_ERR_RANGE | DEV_ERR_ORDER))) {
         // rare runs the streaming kernel leaves to an exact second look
         launch_postings_fixup(ix->sorted_rows, ix->R, ix->fmt, ix->post_w, err_dev, ix->stream);
@@ -555,6 +651,7 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     ix->has_dead = false;
     ix->dead_rows = 0;
     ix->sorted_rows = nullptr;
+    ix->unsorted_rows = nullptr;
     ix->h_row_ptr.resize((size_t)in->n_terms + 1);  // filled by the first search; sized here so that a search never allocates them
     ix->h_news_ptr.resize(in->n_terms);
     ix->h_list_len.resize((size_t)in->n_terms * 2);
@@ -742,46 +839,86 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     }
 
     lap("build of the segment");
-    // ---- in every segment that exists, the rows of the changed units die
+    // ---- everything that can fail for want of memory or for the sizes involved happens before a row of the index is
+    // touched: a failure up to here leaves the index as it was
     const std::vector<sebm25_index*> segs = all_segments(ix);
-    HIP_TRY(ix, ix->upd_counts.ensure(segs.size() * 4 * 8));
-    HIP_TRY(ix, hipMemsetAsync(ix->upd_counts.p, 0, segs.size() * 4 * 8, ix->stream));
-    for (size_t s = 0; s < segs.size(); ++s) {
-        sebm25_index* g = segs[s];
-        if ((rc = ensure_dead_bitmaps(ix, g))) return rc;
-        launch_tombstone(g->sorted_rows, g->R, g->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(),
-                         ix->chg_coarse.as<uint32_t>(), cw, c_words, shift, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
-                         g->term_rows.as<uint32_t>(), ix->upd_counts.as<unsigned long long>() + 4 * s, ix->stream);
-        launch_bitmap_or(g->dead_web.as<uint32_t>(), ix->chg_web.as<uint32_t>(), (uint32_t)(((size_t)g->n_docs + 31) / 32), ix->stream);
-        launch_bitmap_or(g->dead_news.as<uint32_t>(), ix->chg_news.as<uint32_t>(), (uint32_t)(((size_t)g->n_articles + 31) / 32), ix->stream);
+    auto give_up = [&](int code) {   // error text already set on ix
+        sebm25_destroy(seg);
+        return code;
+    };
+    {
+        // the fold of this update's rows with those of the update segment that is there repacks both to the row format of
+        // the id spaces as they will be
+        RowFmt nf;
+        nf.term_bits = bits_for(V);
+        nf.unit_bits = bits_for(std::max<uint64_t>(std::max(n_docs, n_arts), 1));
+        nf.tf_bits = 61 - nf.term_bits - nf.unit_bits;
+        uint64_t n_upd = seg->R;
+        bool narrow = false;
+        for (const sebm25_index* d : ix->deltas) {
+            n_upd += d->R - d->dead_rows;
+            narrow |= nf.tf_bits < d->fmt.tf_bits && nf.tf_bits < 32;
+        }
+        if (!ix->deltas.empty() && narrow)
+            return give_up(fail(ix, SEBM25_E_RANGE, "update: the grown id spaces leave too few bits for tf in the packed row (rebuild)"));
+        if (n_upd > MAX_ROWS) return give_up(fail(ix, SEBM25_E_RANGE, "update: more than 2^32 - 4096 rows in the update segments (compact)"));
     }
-    HIP_TRY(ix, hipGetLastError());
+    auto prepare = [&]() -> int {
+        int r;
+        HIP_TRY(ix, ix->upd_counts.ensure(segs.size() * 4 * 8));
+        for (sebm25_index* g : segs) {
+            if ((r = ensure_dead_bitmaps(ix, g))) return r;
+            if ((r = ensure_sorted_rows(ix, g))) return r;
+        }
+        if ((r = grow_keep(ix, ix->doc_len, (size_t)ix->n_docs_cur * 4, std::max<size_t>(n_docs, 1) * 4))) return r;
+        if ((r = grow_keep(ix, ix->idf, (size_t)ix->V_cur * 8, (size_t)V * 8))) return r;
+        if ((r = grow_keep(ix, ix->idf_used, (size_t)ix->V_cur * 8, (size_t)V * 8))) return r;
+        const size_t sums_held = ix->deltas.empty() ? 0 : (size_t)ix->V_cur * 4;
+        if ((r = grow_keep(ix, ix->df_sum, sums_held, (size_t)V * 4))) return r;
+        if ((r = grow_keep(ix, ix->term_rows_sum, sums_held, (size_t)V * 4))) return r;
+        HIP_TRY(ix, hipMemsetAsync(ix->upd_counts.p, 0, segs.size() * 4 * 8, ix->stream));
+        return SEBM25_OK;
+    };
+    if ((rc = prepare())) return give_up(rc);
+
+    // ---- from here on rows change.  Only a failing HIP call can interrupt it; the handle then counts as unbuilt, so that a
+    // half-updated index is never searched.
+    ix->finalized = false;
     std::vector<unsigned long long> counts(segs.size() * 4);
-    HIP_TRY(ix, hipMemcpyAsync(counts.data(), ix->upd_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, ix->stream));
-
-    lap("dead rows");
-    // ---- per-doc body lengths: the new segment's for changed docs
-    if ((rc = grow_keep(ix, ix->doc_len, (size_t)ix->n_docs_cur * 4, std::max<size_t>(n_docs, 1) * 4))) return rc;
-    launch_doc_len_merge(ix->doc_len.as<uint32_t>(), seg->doc_len.as<uint32_t>(), ix->chg_web.as<uint32_t>(), n_docs, ix->stream);
-
+    uint64_t h[3];
+    auto apply = [&]() -> int {
+        // in every segment that exists, the rows of the changed units die
+        for (size_t s = 0; s < segs.size(); ++s) {
+            sebm25_index* g = segs[s];
+            launch_tombstone(g->sorted_rows, g->R, g->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(),
+                             ix->chg_coarse.as<uint32_t>(), cw, c_words, shift, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
+                             g->term_rows.as<uint32_t>(), ix->upd_counts.as<unsigned long long>() + 4 * s, ix->stream);
+            launch_bitmap_or(g->dead_web.as<uint32_t>(), ix->chg_web.as<uint32_t>(), (uint32_t)(((size_t)g->n_docs + 31) / 32), ix->stream);
+            launch_bitmap_or(g->dead_news.as<uint32_t>(), ix->chg_news.as<uint32_t>(), (uint32_t)(((size_t)g->n_articles + 31) / 32), ix->stream);
+        }
+        HIP_TRY(ix, hipGetLastError());
+        HIP_TRY(ix, hipMemcpyAsync(counts.data(), ix->upd_counts.p, counts.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+        lap("dead rows");
+        // per-doc body lengths: the new segment's for changed docs
+        launch_doc_len_merge(ix->doc_len.as<uint32_t>(), seg->doc_len.as<uint32_t>(), ix->chg_web.as<uint32_t>(), n_docs, ix->stream);
+        // document totals from the documents columns as they are now (bm25_stats.py:9,12)
+        uint64_t* scal = ix->scalars.as<uint64_t>();
+        HIP_TRY(ix, hipMemsetAsync(scal + 2, 0, 24, ix->stream));
+        launch_doc_stats(seg->wc_dev, ix->doc_len.as<uint32_t>(), seg->flags_dev, n_docs, scal + 2, ix->stream);
+        HIP_TRY(ix, hipGetLastError());
+        HIP_TRY(ix, hipMemcpyAsync(h, scal + 2, 24, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+        return SEBM25_OK;
+    };
+    if ((rc = apply())) {
+        ix->built = false;
+        return give_up(rc);
+    }
     // ---- the handle now spans the new id spaces
     if (n_docs > ix->n_docs_cur) ix->has_rank_web = false;      // the rank arrays no longer cover every unit: the caller sets them again
     if (n_arts > ix->n_articles_cur) ix->has_rank_news = false;
     ix->deltas.push_back(seg);
     ix->V_cur = V; ix->n_docs_cur = n_docs; ix->n_articles_cur = n_arts;
-    HIP_TRY(ix, ix->idf.ensure((size_t)V * 8));
-    HIP_TRY(ix, ix->idf_used.ensure((size_t)V * 8));
-    if ((rc = sum_term_counts(ix))) return rc;
-
-    lap("doc lengths, term sums");
-    // ---- document totals from the documents columns as they are now (bm25_stats.py:9,12)
-    uint64_t* scal = ix->scalars.as<uint64_t>();
-    HIP_TRY(ix, hipMemsetAsync(scal + 2, 0, 24, ix->stream));
-    launch_doc_stats(seg->wc_dev, ix->doc_len.as<uint32_t>(), seg->flags_dev, n_docs, scal + 2, ix->stream);
-    HIP_TRY(ix, hipGetLastError());
-    uint64_t h[3];
-    HIP_TRY(ix, hipMemcpyAsync(h, scal + 2, 24, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
     uint64_t P_all = seg->P;
     for (size_t s = 0; s < segs.size(); ++s) {
         sebm25_index* g = segs[s];
@@ -795,10 +932,21 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
     ix->local_totals.n_wc = h[1];
     ix->local_totals.sum_wc = h[2];
     ix->local_totals.n_postings = P_all;
-    ix->finalized = false;
-    lap("document totals");
-    if (ix->deltas.size() > 1 && (rc = fold_deltas(ix))) return rc;
+    lap("doc lengths, document totals");
+    // one update segment again.  The fold only saves later searches a segment: when it cannot be done (memory), the
+    // segments stay as they are, which is a valid index
+    bool summed = false;
+    if (ix->deltas.size() > 1) {
+        if (fold_deltas(ix) == SEBM25_OK)
+            summed = true;   // the fold ends with the sums over the segments
+        else
+            (void)hipGetLastError();
+    }
     lap("update segments folded");
+    if (!summed && (rc = sum_term_counts(ix))) {   // buffers are in place: only a failing HIP call ends up here
+        ix->built = false;
+        return rc;
+    }
     return SEBM25_OK;
 }
 
@@ -886,6 +1034,7 @@ int do_compact(sebm25_index* ix) {
     const uint64_t total = ix->R - ix->dead_rows + n_upd;
     if (total > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "compact: more than 2^32 - 4096 live rows");
     if ((rc = ensure_dead_bitmaps(ix, ix))) return rc;
+    if ((rc = ensure_sorted_rows(ix, ix))) return rc;
     // ---- merge: the base segment's rows are sorted already.  Live rows per tile, their running sum, the insertion
     // point of every update row, then one pass that writes both to their merged places.
     // The base segment's sorted rows sit in one of its two sort buffers and its posting slots in the other; the
@@ -976,6 +1125,7 @@ int sebm25_create(int device, sebm25_index** out) {
     if (!ix) return fail(nullptr, SEBM25_E_NOMEM, "create: out of host memory");
     ix->device = device;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
+    if (const char* e = getenv("SEBM25_FUSED_POSTINGS")) ix->fused = atoi(e) != 0;  // 0: always the separate posting pass
     {
         // set-up of sebm25_search_noalloc: this GPU's address of the fixed device array and the pinned host plan storage
         DeviceGuard g(device);
@@ -1240,6 +1390,7 @@ int sebm25_get_info(sebm25_index* ix, sebm25_index_info* out) {
     out->unit_bits = (uint32_t)ix->fmt.unit_bits;
     out->tf_bits = (uint32_t)ix->fmt.tf_bits;
     out->sort_passes = ix->n_pass;
+    out->fused_postings = ix->built_fused ? 1u : 0u;
     return SEBM25_OK;
     ABI_CATCH(ix)
 }

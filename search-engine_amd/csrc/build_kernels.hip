@@ -282,6 +282,243 @@ __global__ __launch_bounds__(256) void k_sort_seg_apply(uint32_t* group_tot, uin
     }
 }
 
+// 32-bit views of the packed row's fields.  The 64-bit shifts and compares of RowFmt cost
+// several times a 32-bit operation; here every test is a mask on one or both halves of the row
+// and every extraction a funnel shift.  All members are wave-uniform.
+struct RowBits {
+    uint32_t key_hi, key_lo;  // (term, source, unit) bits
+    uint32_t term_hi;         // term bits: always inside the high word (term ids are 32-bit)
+    uint32_t src_hi, src_lo;  // the source bit
+    uint32_t big_hi, big_lo;  // tf bits from 2^24 up
+    uint32_t unit_mask, tf24_mask;
+    int term_sh, unit_sh, fc_sh;
+    __device__ explicit RowBits(const RowFmt& f) {
+        const uint64_t key = ~0ull << f.key_shift(), src = 1ull << f.src_shift();
+        const uint64_t tf = (1ull << f.tf_bits) - 1ull, big = tf & ~0xFFFFFFull;
+        key_hi = (uint32_t)(key >> 32); key_lo = (uint32_t)key;
+        term_hi = (uint32_t)((~0ull << f.term_shift()) >> 32);
+        src_hi = (uint32_t)(src >> 32); src_lo = (uint32_t)src;
+        big_hi = (uint32_t)(big >> 32); big_lo = (uint32_t)big;
+        unit_mask = (uint32_t)((1ull << f.unit_bits) - 1ull);
+        tf24_mask = (uint32_t)(tf & 0xFFFFFFull);
+        term_sh = f.term_shift() - 32; unit_sh = f.unit_shift(); fc_sh = f.tf_bits;
+    }
+};
+__device__ __forceinline__ bool key_differs(const RowBits& b, uint64_t x, uint64_t y) {
+    return (((hi32(x) ^ hi32(y)) & b.key_hi) | ((lo32(x) ^ lo32(y)) & b.key_lo)) != 0u;
+}
+__device__ __forceinline__ bool is_news(const RowBits& b, uint64_t r) {
+    return ((hi32(r) & b.src_hi) | (lo32(r) & b.src_lo)) != 0u;
+}
+__device__ __forceinline__ bool tf_big(const RowBits& b, uint64_t r) {
+    return ((hi32(r) & b.big_hi) | (lo32(r) & b.big_lo)) != 0u;
+}
+// weight of one row in tenths, tf < 2^24: web tf * {32, 17, 10}[field code] (W = 3.2 / 1.7 / 1.0,
+// search_service.py:19-27), news 10 * tf (:84-87)
+__device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool news) {
+    // the multiplier by table: byte fc of 0x0A11200A (10, 32, 17, 10), selected with the field code
+    // taken from the row already multiplied by 8 (fc_sh >= 8 because tf has at least 8 bits)
+    const uint32_t sh = shr_lo32(r, b.fc_sh - 3) & 0x18u;
+    const uint32_t mult = news ? 10u : __builtin_amdgcn_ubfe(0x0A11200Au, sh, 8u);
+    return __umul24(lo32(r) & b.tf24_mask, mult);
+}
+
+// ------------------------------------------------------------------ posting slots from the last pass ---
+// Outputs of the last sort pass when it writes posting slots (k_sort_scatter_tile<2, true>).
+struct PostOut {
+    uint32_t* post_unit;  // [R + POST_PAD] unit of every sorted row
+    uint32_t* post_w;     // [R + POST_PAD] weight (tenths) at the head of every kept run, POST_HOLE elsewhere
+    uint32_t* news_ptr;   // [n_terms], preset to 0xFFFFFFFF: first news slot of the term (atomic minimum)
+    uint32_t* dup;        // [n_terms], zeroed: web rows of the term that are not the head of their run
+    uint4* partials;      // [chunks]: kept postings, web heads, kept web postings of the tile
+};
+constexpr uint32_t POST_NBR = 64;  // rows looked at on either side of a tile
+// aliases the per-wave digit counters, which are dead once the tile is reordered
+struct PostTileShared {
+    uint64_t nbr[2 * POST_NBR];  // rows before the tile (nearest first), then rows behind it
+    uint64_t first, last;        // first and last row of the tile in input order
+    uint32_t n_tail, n_ahead;    // neighbours (counted from the tile) that share the first / last row's lower key bits
+    uint32_t tot[3];
+};
+static_assert(sizeof(PostTileShared) <= SORT_WAVES * SORT_MAX_BINS * 2, "fits the digit counters");
+
+// rows_s holds the tile ordered by the digit of this pass (stable), i.e. by term, and inside a term in input
+// order: (source, unit) ascending, the field rows of one unit next to each other.  base[d] + p is the slot of
+// the row at place p.  Wave w takes places [512 w, 512 w + 512) in rounds of 64, neighbours through lane
+// shifts as in k_postings.  What the tile cannot see:
+//  - whether the first row of a run continues a run of the tile before.  Rows of one (term, source, unit) agree
+//    in every key bit below this pass's digit, and the input is ordered by those bits, so such a run can only
+//    be one whose lower key bits equal those of the tile's first input row; it is a continuation iff one of
+//    the rows before the tile that still share those bits (a handful: the rows of one unit whose terms share
+//    the earlier digits) has the same full key.
+//  - rows of a run behind the tile's end: the same with the tile's last input row and the rows behind it.
+// More than POST_NBR such neighbours, runs of more than three rows and tf >= 2^24 raise DEV_NEED_FIXUP: the
+// host then sorts the rows out and runs k_postings over them.
+// df is not counted here: a term's web heads are its web rows minus the web rows that are not heads, and only
+// the latter (about 3 % of the rows of a crawled corpus) cost an atomic.
+__device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t* base, PostTileShared* ps, uint32_t n_tile,
+                                          uint64_t tile0, uint64_t end, uint64_t R, uint32_t chunk, int shift, uint32_t mask,
+                                          const RowFmt& fmt, uint64_t nbr, uint64_t edge_row, uint64_t row0, uint32_t* err,
+                                          const PostOut& po) {
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const RowBits rb(fmt);
+    const uint64_t cut = (~0ull << fmt.key_shift()) & ~((uint64_t)mask << shift);  // key bits below this pass's digit
+    const uint32_t cut_hi = hi32(cut), cut_lo = lo32(cut);
+    auto cut_equal = [&](uint64_t a, uint64_t b) {
+        return (((hi32(a) ^ hi32(b)) & cut_hi) | ((lo32(a) ^ lo32(b)) & cut_lo)) == 0u;
+    };
+    if (wave == 0u) {
+        const uint64_t first = lane_bcast<0>(row0);
+        const uint64_t mm = __ballot(tile0 > lane && cut_equal(nbr, first));
+        const uint32_t n = mm == ~0ull ? POST_NBR : (uint32_t)__ffsll((unsigned long long)~mm) - 1u;
+        ps->nbr[lane] = nbr;
+        if (lane == 0) {
+            ps->first = first;
+            ps->n_tail = n;
+            ps->tot[0] = ps->tot[1] = ps->tot[2] = 0;
+            if (n == POST_NBR) atomicOr(err, DEV_NEED_FIXUP);
+        }
+    } else if (wave == 1u) {
+        const uint64_t mm = __ballot(end + lane < R && cut_equal(nbr, edge_row));
+        const uint32_t n = mm == ~0ull ? POST_NBR : (uint32_t)__ffsll((unsigned long long)~mm) - 1u;
+        ps->nbr[POST_NBR + lane] = nbr;
+        if (lane == 0) {
+            ps->last = edge_row;
+            ps->n_ahead = n;
+            if (n == POST_NBR) atomicOr(err, DEV_NEED_FIXUP);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps->n_tail);
+    const uint32_t n_ahead = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps->n_ahead);
+    const uint64_t first = ps->first, last = ps->last;
+    const uint32_t wb = wave * (64u * SORT_ITEMS);
+    uint32_t n_kept = 0, n_wh = 0, n_kept_web = 0;
+    if (wb < n_tile) {
+        const uint64_t lt = lanemask_lt();
+        // a row behind the tile reads as a row of another unit, the row before it as one of another term
+        const uint64_t sent = rows_s[n_tile - 1u] ^ (1ull << fmt.key_shift());
+        uint64_t x[SORT_ITEMS + 1];
+#pragma unroll
+        for (int j = 0; j <= SORT_ITEMS; ++j) {
+            const uint32_t p = wb + (uint32_t)j * 64u + (j < SORT_ITEMS ? lane : (lane & 3u));
+            const uint64_t r = rows_s[min(p, n_tile - 1u)];
+            x[j] = p < n_tile ? r : sent;
+        }
+        uint64_t before = wave ? rows_s[wb - 1u] : rows_s[0] ^ (1ull << 63);
+        const uint32_t ts_hi = rb.term_hi | rb.src_hi, ts_lo = rb.src_lo;
+
+        // ---- per row the word v = tenths | differs-from-predecessor << 31 (also of the first rows behind the wave's)
+        uint32_t v[SORT_ITEMS + 1];
+        bool news[SORT_ITEMS], term_new[SORT_ITEMS], ts_new[SORT_ITEMS];
+        uint32_t seen_hi = 0, seen_lo = 0;
+#pragma unroll
+        for (int j = 0; j <= SORT_ITEMS; ++j) {
+            const uint64_t xx = x[j];
+            const uint32_t dh = hi32(xx) ^ lane_up1_edge(hi32(xx), hi32(before));
+            const uint32_t dl = lo32(xx) ^ lane_up1_edge(lo32(xx), lo32(before));
+            const bool nw = is_news(rb, xx);
+            const bool differs = ((dh & rb.key_hi) | (dl & rb.key_lo)) != 0u;
+            v[j] = tenths24(rb, xx, nw) | (differs ? 0x80000000u : 0u);
+            if (j < SORT_ITEMS) {
+                news[j] = nw;
+                term_new[j] = (dh & rb.term_hi) != 0u;
+                ts_new[j] = ((dh & ts_hi) | (dl & ts_lo)) != 0u;
+                seen_hi |= hi32(xx);
+                seen_lo |= lo32(xx);
+                before = lane_bcast<63>(xx);
+            }
+        }
+        if (__ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
+
+        constexpr uint32_t NO_TERM = 0xFFFFFFFFu;
+        uint32_t run_term = NO_TERM, run_cnt = 0;  // rows that are no heads, of the term the last rounds consisted of
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const uint32_t p = wb + (uint32_t)j * 64u + lane;
+            const bool valid = p < n_tile;
+            const uint64_t vm = __ballot(valid);
+            const uint64_t x0 = x[j];
+            const uint32_t n1 = lane_dn1_edge(v[j], (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 0));
+            const uint32_t n2 = lane_dn1_edge(n1, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 1));
+            const uint32_t n3 = lane_dn1_edge(n2, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 2));
+            const uint32_t term = hi32(x0) >> rb.term_sh;
+            const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
+            const uint32_t slot = base[shr_lo32(x0, shift) & mask] + p;
+            bool head = valid & ((v[j] >> 31) != 0u);
+            // the first row of a run that may have begun before the tile
+            const bool c0 = head & cut_equal(x0, first);
+            if (n_tail != 0u && __ballot(c0) != 0ull) {
+                if (c0)
+                    for (uint32_t i = 0; i < n_tail; ++i)
+                        if (!key_differs(rb, ps->nbr[i], x0)) head = false;
+            }
+            const bool webhead = head & !news[j];
+            const bool kept = head & (news[j] | ((shr_lo32(x0, rb.fc_sh) & 3u) != 3u));
+            const uint64_t km = __ballot(kept), wm = __ballot(webhead);
+            const bool same1 = !(n1 >> 31), same2 = same1 & !(n2 >> 31), same3 = same2 & !(n3 >> 31);
+            uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
+            uint32_t run_rows = 1u + (same1 ? 1u : 0u) + (same2 ? 1u : 0u) + (same3 ? 1u : 0u);
+            // a run that may go on behind the tile
+            const bool c1 = kept & cut_equal(x0, last);
+            if (n_ahead != 0u && __ballot(c1) != 0ull) {
+                if (c1)
+                    for (uint32_t i = 0; i < n_ahead; ++i) {
+                        const uint64_t y = ps->nbr[POST_NBR + i];
+                        if (!key_differs(rb, y, x0)) {
+                            w += tenths24(rb, y, news[j]);
+                            ++run_rows;
+                        }
+                    }
+            }
+            if (__ballot(kept & (run_rows > 3u)) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
+            if (valid) {
+                po.post_unit[slot] = unit;
+                po.post_w[slot] = kept ? w : POST_HOLE;
+            }
+            if (__ballot(kept & (w >= 0xFFFFu)) && lane == 0) atomicOr(err, DEV_BIG_WEIGHT);
+            if (valid & news[j] & ts_new[j]) atomicMin(&po.news_ptr[term], slot);
+            n_kept += (uint32_t)__popcll(km);
+            n_wh += (uint32_t)__popcll(wm);
+            n_kept_web += (uint32_t)__popcll(km & wm);
+
+            // web rows that are not heads, per term: rounds of one term only extend a running count
+            const uint64_t dm = __ballot(valid & !news[j] & !head);
+            if (dm != 0ull) {
+                const uint64_t starts = (__ballot(term_new[j]) | 1ull) & vm;
+                if (starts == 1ull) {
+                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
+                    if (t0 != run_term) {
+                        if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
+                        run_term = t0;
+                        run_cnt = 0;
+                    }
+                    run_cnt += (uint32_t)__popcll(dm);
+                } else {
+                    if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
+                    run_term = NO_TERM;
+                    run_cnt = 0;
+                    const uint64_t ends = vm & ((starts >> 1) | ~(vm >> 1));  // the last lane of every term segment
+                    if ((ends >> lane) & 1ull) {
+                        const uint64_t upto = lt | (1ull << lane);
+                        const int s0 = 63 - __clzll((long long)(starts & upto));
+                        const uint32_t cnt = (uint32_t)__popcll(dm & upto & ~((1ull << s0) - 1ull));
+                        if (cnt) atomicAdd(&po.dup[term], cnt);
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            if (run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
+            atomicAdd(&ps->tot[0], n_kept);
+            atomicAdd(&ps->tot[1], n_wh);
+            atomicAdd(&ps->tot[2], n_kept_web);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) po.partials[chunk] = make_uint4(ps->tot[0], ps->tot[1], ps->tot[2], 0u);
+}
+
 constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-length counters
 
 // ------------------------------------------------------------------ scatter (downsweep) ---
@@ -296,11 +533,18 @@ constexpr int DL_SPAN = SORT_THREADS;  // doc ids covered by a tile's LDS body-l
 // reordered into it).  52 KB of LDS and 80 registers put three workgroups on a CU, which is what
 // hides the latency of a tile's phases (load, rank, offsets, reorder, store); a looped form with
 // the next tile's loads issued ahead of the stores, two workgroups per CU, was 45 % slower.
-template <int MODE>
+//
+// POST (packed rows, last pass of a sort on the term bits of unit-major rows): the pass writes no rows.  Its
+// tile, reordered by digit in LDS, holds every (term, source, unit) run of the final order in one piece
+// except the runs of the one unit a tile boundary cuts, so each row's posting slot (unit; weight of the run
+// at its head, a hole elsewhere) is written straight to the slot the row would have been scattered to.
+// See the posting phase at the end of the kernel.
+template <int MODE, bool POST>
 __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows raw, const uint64_t* packed, uint64_t* dst,
                                                                     uint64_t R, uint32_t G, int shift, int bits,
                                                                     BuildCtx ctx, const unsigned short* prefix,
-                                                                    const uint32_t* group_off) {
+                                                                    const uint32_t* group_off, PostOut po) {
+    static_assert(!POST || MODE == 2, "posting slots are written from packed rows");
     __shared__ __align__(16) unsigned short whist[SORT_WAVES][SORT_MAX_BINS];  // per-wave digit counts, then local slots
     __shared__ __align__(16) uint64_t rows_s[SORT_TILE];                       // the tile, locally ordered by digit
     __shared__ __align__(8) uint32_t base[SORT_MAX_BINS];  // first the chunk's write base per digit, then global minus local slot
@@ -365,6 +609,14 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
         prev_m = raw.meta[ip];
         first_u = raw.unit[tile0];
         first_m = raw.meta[tile0];
+    }
+    // POST: the 64 rows before the tile (wave 0, nearest first) and the 64 rows behind it (wave 1, with the
+    // tile's last row), from clamped addresses
+    uint64_t nbr = 0, edge_row = 0;
+    if (POST && wave < 2u) {
+        const uint64_t i = wave == 0u ? (tile0 > lane ? tile0 - 1u - lane : 0ull) : min(end + lane, R - 1u);
+        nbr = packed[i];
+        edge_row = packed[end - 1u];
     }
     asm volatile("" ::: "memory");  // keeps the loads below from moving up between the row loads
     load_bases();
@@ -582,15 +834,20 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     }
     __syncthreads();
 
-    // ---- write out: consecutive threads hold consecutive slots of a digit's run
+    if constexpr (!POST) {
+        // ---- write out: consecutive threads hold consecutive slots of a digit's run
 #pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-        const uint32_t p = t + (uint32_t)j * SORT_THREADS;
-        if (p < n_tile) {
-            const uint64_t r = rows_s[p];
-            const uint32_t d = shr_lo32(r, shift) & mask;
-            dst[(uint32_t)(base[d] + p)] = r;
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const uint32_t p = t + (uint32_t)j * SORT_THREADS;
+            if (p < n_tile) {
+                const uint64_t r = rows_s[p];
+                const uint32_t d = shr_lo32(r, shift) & mask;
+                dst[(uint32_t)(base[d] + p)] = r;
+            }
         }
+    } else {
+        post_tile(rows_s, base, reinterpret_cast<PostTileShared*>(&whist[0][0]), n_tile, tile0, end, R, chunk, shift, mask, fmt,
+                  nbr, edge_row, row[0], ctx.err, po);
     }
 }
 
@@ -627,12 +884,64 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
                          int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
                          hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
+    const PostOut none{};
     if (mode == 0)
-        hipLaunchKernelGGL(k_sort_scatter_tile<0>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
+        hipLaunchKernelGGL((k_sort_scatter_tile<0, false>), grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, none);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_sort_scatter_tile<1>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
+        hipLaunchKernelGGL((k_sort_scatter_tile<1, false>), grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, none);
     else
-        hipLaunchKernelGGL(k_sort_scatter_tile<2>, grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off);
+        hipLaunchKernelGGL((k_sort_scatter_tile<2, false>), grid, block, 0, st, raw, packed, dst, R, G, shift, bits, ctx, prefix, group_off, none);
+}
+
+__global__ __launch_bounds__(1024) void k_postings_totals(const uint4* partials, uint32_t n_chunks, unsigned long long* totals);
+
+void launch_sort_scatter_post(const uint64_t* packed, uint64_t R, uint32_t G, int shift, int bits, const BuildCtx& ctx,
+                              const unsigned short* prefix, const uint32_t* group_off, uint32_t* post_unit, uint32_t* post_w,
+                              uint32_t* news_ptr, uint32_t* dup, uint32_t* tmp, uint64_t* totals, hipStream_t st) {
+    dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
+    const PostOut po{post_unit, post_w, news_ptr, dup, reinterpret_cast<uint4*>(tmp)};
+    hipLaunchKernelGGL((k_sort_scatter_tile<2, true>), grid, block, 0, st, RawRows{}, packed, (uint64_t*)nullptr, R, G, shift, bits,
+                       ctx, prefix, group_off, po);
+    hipLaunchKernelGGL(k_postings_totals, dim3(1), dim3(1024), 0, st, po.partials, G, reinterpret_cast<unsigned long long*>(totals));
+}
+
+size_t scatter_post_tmp_words(uint32_t G) { return (size_t)G * 4; }
+
+// First slot of every term from the offsets of a two-pass sort on the term bits (no pass over the sorted rows
+// is needed for it).  The last pass's input is ordered by the low term bits L, its output by (high bits h, L),
+// so term (h, L) starts where the last pass puts the first row of digit h at or behind the first input row of L:
+// the write base of that row's chunk for h plus the rows of digit h the chunk holds before it.  One workgroup
+// per L counts those rows (fewer than one tile).  Terms without rows get the first slot of the next term.
+__global__ __launch_bounds__(256) void k_first_slots(const uint64_t* rows, uint32_t R, uint32_t G, int shift, int bits1, int bits2,
+                                                     const uint32_t* bin_start1, const unsigned short* prefix,
+                                                     const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
+                                                     uint32_t* row_ptr) {
+    __shared__ uint32_t hist[SORT_MAX_BINS];
+    const uint32_t L = blockIdx.x, nb2 = 1u << bits2;
+    for (uint32_t x = threadIdx.x; x < nb2; x += 256u) hist[x] = 0;
+    __syncthreads();
+    const uint32_t b = bin_start1[L];  // first input row whose low term bits are L or more (R: none)
+    const uint32_t c = b / (uint32_t)SORT_TILE;
+    for (uint32_t i = c * (uint32_t)SORT_TILE + threadIdx.x; i < b; i += 256u) atomicAdd(&hist[shr_lo32(rows[i], shift) & (nb2 - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t h = threadIdx.x; h < nb2; h += 256u) {
+        const uint64_t t = ((uint64_t)h << bits1) | L;
+        if (t >= n_terms) continue;
+        uint32_t at;
+        if (c < G)
+            at = group_off[(size_t)(c / SORT_GROUP) * nb2 + h] + prefix[(size_t)c * nb2 + h] + hist[h];
+        else  // behind the last row: the end of digit h's rows
+            at = h + 1u < nb2 ? bin_start2[h + 1u] : R;
+        row_ptr[t] = at;
+    }
+    if (L == 0 && threadIdx.x == 0) row_ptr[n_terms] = R;
+}
+
+void launch_first_slots(const uint64_t* rows, uint64_t R, uint32_t G, int shift, int bits1, int bits2, const uint32_t* bin_start1,
+                        const unsigned short* prefix, const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
+                        uint32_t* row_ptr, hipStream_t st) {
+    hipLaunchKernelGGL(k_first_slots, dim3(1u << bits1), dim3(256), 0, st, rows, (uint32_t)R, G, shift, bits1, bits2, bin_start1, prefix,
+                       group_off, bin_start2, n_terms, row_ptr);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------
@@ -739,46 +1048,6 @@ void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStrea
 // or prefix-summed first, so the rows are read once.  Each wavefront streams its own contiguous
 // range of rows (no workgroup barriers): 64 consecutive rows per load, neighbours compared
 // through lane shifts, coalesced slot stores.
-// 32-bit views of the packed row's fields.  The 64-bit shifts and compares of RowFmt cost
-// several times a 32-bit operation; here every test is a mask on one or both halves of the row
-// and every extraction a funnel shift.  All members are wave-uniform.
-struct RowBits {
-    uint32_t key_hi, key_lo;  // (term, source, unit) bits
-    uint32_t term_hi;         // term bits: always inside the high word (term ids are 32-bit)
-    uint32_t src_hi, src_lo;  // the source bit
-    uint32_t big_hi, big_lo;  // tf bits from 2^24 up
-    uint32_t unit_mask, tf24_mask;
-    int term_sh, unit_sh, fc_sh;
-    __device__ explicit RowBits(const RowFmt& f) {
-        const uint64_t key = ~0ull << f.key_shift(), src = 1ull << f.src_shift();
-        const uint64_t tf = (1ull << f.tf_bits) - 1ull, big = tf & ~0xFFFFFFull;
-        key_hi = (uint32_t)(key >> 32); key_lo = (uint32_t)key;
-        term_hi = (uint32_t)((~0ull << f.term_shift()) >> 32);
-        src_hi = (uint32_t)(src >> 32); src_lo = (uint32_t)src;
-        big_hi = (uint32_t)(big >> 32); big_lo = (uint32_t)big;
-        unit_mask = (uint32_t)((1ull << f.unit_bits) - 1ull);
-        tf24_mask = (uint32_t)(tf & 0xFFFFFFull);
-        term_sh = f.term_shift() - 32; unit_sh = f.unit_shift(); fc_sh = f.tf_bits;
-    }
-};
-__device__ __forceinline__ bool key_differs(const RowBits& b, uint64_t x, uint64_t y) {
-    return (((hi32(x) ^ hi32(y)) & b.key_hi) | ((lo32(x) ^ lo32(y)) & b.key_lo)) != 0u;
-}
-__device__ __forceinline__ bool is_news(const RowBits& b, uint64_t r) {
-    return ((hi32(r) & b.src_hi) | (lo32(r) & b.src_lo)) != 0u;
-}
-__device__ __forceinline__ bool tf_big(const RowBits& b, uint64_t r) {
-    return ((hi32(r) & b.big_hi) | (lo32(r) & b.big_lo)) != 0u;
-}
-// weight of one row in tenths, tf < 2^24: web tf * {32, 17, 10}[field code] (W = 3.2 / 1.7 / 1.0,
-// search_service.py:19-27), news 10 * tf (:84-87)
-__device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool news) {
-    // the multiplier by table: byte fc of 0x0A11200A (10, 32, 17, 10), selected with the field code
-    // taken from the row already multiplied by 8 (fc_sh >= 8 because tf has at least 8 bits)
-    const uint32_t sh = shr_lo32(r, b.fc_sh - 3) & 0x18u;
-    const uint32_t mult = news ? 10u : __builtin_amdgcn_ubfe(0x0A11200Au, sh, 8u);
-    return __umul24(lo32(r) & b.tf24_mask, mult);
-}
 
 // row_ptr[t] = first slot of term t (left at 0xFFFFFFFF for terms without rows), news_ptr[t] =
 // first news slot of term t (left at 0xFFFFFFFF for terms without news rows), df[t] += web heads of term t (zeroed by
@@ -1081,6 +1350,24 @@ __global__ void k_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t
     if (t >= n_terms) return;
     term_rows[t] = row_ptr[t + 1] - row_ptr[t];
     if (news_ptr[t] == 0xFFFFFFFFu) news_ptr[t] = row_ptr[t + 1];
+}
+
+// the same when the last sort pass wrote the posting slots: df_dup holds, per term, the web rows that are not the
+// head of their (term, unit) run and becomes df = web rows - those (bm25_stats.py:20: COUNT(DISTINCT doc_id))
+__global__ void k_term_stats_dup(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows,
+                                 uint32_t* df_dup) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    const uint32_t b = row_ptr[t], e = row_ptr[t + 1];
+    term_rows[t] = e - b;
+    uint32_t np = news_ptr[t];
+    if (np == 0xFFFFFFFFu) news_ptr[t] = np = e;
+    df_dup[t] = np - b - df_dup[t];
+}
+
+void launch_term_stats_dup(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows, uint32_t* df_dup,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_term_stats_dup, dim3((n_terms + 255) / 256), dim3(256), 0, st, n_terms, row_ptr, news_ptr, term_rows, df_dup);
 }
 
 void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows,

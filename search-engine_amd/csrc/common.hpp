@@ -125,6 +125,20 @@ void launch_sort_offsets(uint32_t* group_tot, uint32_t n_groups, int bits, uint3
 void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t* dst, uint64_t R, uint32_t G, int shift,
                          int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
                          hipStream_t st);
+// the last pass of a two-pass sort on the term bits of unit-major rows, writing posting slots instead of rows:
+// post_unit / post_w [R + POST_PAD], news_ptr preset to 0xFFFFFFFF, dup zeroed (per term: web rows that are not
+// run heads), totals [0] kept, [1] web heads, [5] kept web (zeroed), tmp scatter_post_tmp_words(G) words
+void launch_sort_scatter_post(const uint64_t* packed, uint64_t R, uint32_t G, int shift, int bits, const BuildCtx& ctx,
+                              const unsigned short* prefix, const uint32_t* group_off, uint32_t* post_unit, uint32_t* post_w,
+                              uint32_t* news_ptr, uint32_t* dup, uint32_t* tmp, uint64_t* totals, hipStream_t st);
+size_t scatter_post_tmp_words(uint32_t G);
+// row_ptr[0 .. n_terms] from the offsets of both passes (bin_start1: first input row of every low digit of the
+// last pass's input `rows`; prefix / group_off / bin_start2: the last pass's)
+void launch_first_slots(const uint64_t* rows, uint64_t R, uint32_t G, int shift, int bits1, int bits2, const uint32_t* bin_start1,
+                        const unsigned short* prefix, const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
+                        uint32_t* row_ptr, hipStream_t st);
+void launch_term_stats_dup(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows, uint32_t* df_dup,
+                           hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
 size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);

@@ -54,6 +54,7 @@ class IndexInfo(C.Structure):
         ("n_terms", C.c_uint32), ("n_docs", C.c_uint32), ("n_articles", C.c_uint32),
         ("term_bits", C.c_uint32), ("unit_bits", C.c_uint32), ("tf_bits", C.c_uint32), ("sort_passes", C.c_uint32),
         ("n_segments", C.c_uint32), ("n_dead_rows", C.c_uint64), ("n_update_rows", C.c_uint64),
+        ("fused_postings", C.c_uint32),
     ]
 
 
