@@ -395,121 +395,163 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
     const uint32_t wb = wave * (64u * SORT_ITEMS);
     uint32_t n_kept = 0, n_wh = 0, n_kept_web = 0;
     if (wb < n_tile) {
-        const uint64_t lt = lanemask_lt();
+        // Every yes/no per row is kept as a wave-wide lane mask in scalar registers: masks of plain compares
+        // are free, combining them is scalar work, and only a select or a guarded store turns one back into a
+        // per-lane condition.
+        auto ballot = [](bool c) { return (uint64_t)__builtin_amdgcn_ballot_w64(c); };
+        auto lanes = [](uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
         // a row behind the tile reads as a row of another unit, the row before it as one of another term
         const uint64_t sent = rows_s[n_tile - 1u] ^ (1ull << fmt.key_shift());
-        uint64_t x[SORT_ITEMS + 1];
-#pragma unroll
-        for (int j = 0; j <= SORT_ITEMS; ++j) {
-            const uint32_t p = wb + (uint32_t)j * 64u + (j < SORT_ITEMS ? lane : (lane & 3u));
+        auto row_at = [&](uint32_t p) {
             const uint64_t r = rows_s[min(p, n_tile - 1u)];
-            x[j] = p < n_tile ? r : sent;
-        }
-        uint64_t before = wave ? rows_s[wb - 1u] : rows_s[0] ^ (1ull << 63);
+            return p < n_tile ? r : sent;
+        };
         const uint32_t ts_hi = rb.term_hi | rb.src_hi, ts_lo = rb.src_lo;
-
-        // ---- per row the word v = tenths | differs-from-predecessor << 31 (also of the first rows behind the wave's)
-        uint32_t v[SORT_ITEMS + 1];
-        bool news[SORT_ITEMS], term_new[SORT_ITEMS], ts_new[SORT_ITEMS];
+        const bool check_big = (rb.big_hi | rb.big_lo) != 0u;  // tf can reach 2^24 at all
         uint32_t seen_hi = 0, seen_lo = 0;
-#pragma unroll
-        for (int j = 0; j <= SORT_ITEMS; ++j) {
-            const uint64_t xx = x[j];
-            const uint32_t dh = hi32(xx) ^ lane_up1_edge(hi32(xx), hi32(before));
-            const uint32_t dl = lo32(xx) ^ lane_up1_edge(lo32(xx), lo32(before));
+        // One round ahead of the round being written: per row its own weight in tenths, per round the rows whose key
+        // differs from the row before (df) and the news rows (nm).  Round 8 is the first rows behind the wave's
+        // (lanes 0..2 are looked at).
+        auto stage = [&](uint64_t xx, uint64_t bef, uint32_t& t10, uint64_t& df, uint64_t& nmask) {
+            const uint32_t dh = hi32(xx) ^ lane_up1_edge(hi32(xx), hi32(bef));
+            const uint32_t dl = lo32(xx) ^ lane_up1_edge(lo32(xx), lo32(bef));
             const bool nw = is_news(rb, xx);
-            const bool differs = ((dh & rb.key_hi) | (dl & rb.key_lo)) != 0u;
-            v[j] = tenths24(rb, xx, nw) | (differs ? 0x80000000u : 0u);
-            if (j < SORT_ITEMS) {
-                news[j] = nw;
-                term_new[j] = (dh & rb.term_hi) != 0u;
-                ts_new[j] = ((dh & ts_hi) | (dl & ts_lo)) != 0u;
+            df = ballot(((dh & rb.key_hi) | (dl & rb.key_lo)) != 0u);
+            nmask = ballot(nw);
+            t10 = tenths24(rb, xx, nw);
+            if (check_big) {
                 seen_hi |= hi32(xx);
                 seen_lo |= lo32(xx);
-                before = lane_bcast<63>(xx);
             }
-        }
-        if (__ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
+        };
+        uint64_t x0 = row_at(wb + lane);
+        uint64_t bef = wave ? rows_s[wb - 1u] : rows_s[0] ^ (1ull << 63);
+        uint32_t t0w = 0;
+        uint64_t df0 = 0, nm0 = 0;
+        stage(x0, bef, t0w, df0, nm0);
+        uint64_t fix_m = 0, big_m = 0;
 
         constexpr uint32_t NO_TERM = 0xFFFFFFFFu;
-        uint32_t run_term = NO_TERM, run_cnt = 0;  // rows that are no heads, of the term the last rounds consisted of
+        uint32_t run_term = NO_TERM, run_cnt = 0;  // web rows that are no heads, of the term the last rounds ended with
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const uint32_t p = wb + (uint32_t)j * 64u + lane;
-            const bool valid = p < n_tile;
-            const uint64_t vm = __ballot(valid);
-            const uint64_t x0 = x[j];
-            const uint32_t n1 = lane_dn1_edge(v[j], (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 0));
-            const uint32_t n2 = lane_dn1_edge(n1, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 1));
-            const uint32_t n3 = lane_dn1_edge(n2, (uint32_t)__builtin_amdgcn_readlane((int)v[j + 1], 2));
+            const uint64_t x1 = row_at(wb + (uint32_t)(j + 1) * 64u + (j + 1 < SORT_ITEMS ? lane : (lane & 3u)));
+            const uint64_t bef1 = lane_bcast<63>(x0);
+            uint32_t t1w = 0;
+            uint64_t df1 = 0, nm1 = 0;
+            stage(x1, bef1, t1w, df1, nm1);
+
+            const uint64_t vm = ballot(p < n_tile);
+            // weights of the next two rows: lane shifts; at the wave edge the first lanes of the next round
+            const uint32_t n1 = lane_dn1_edge(t0w, (uint32_t)__builtin_amdgcn_readlane((int)t1w, 0));
+            const uint32_t n2 = lane_dn1_edge(n1, (uint32_t)__builtin_amdgcn_readlane((int)t1w, 1));
+            // rows whose next one / two / three rows continue their run
+            const uint64_t s1 = ~((df0 >> 1) | (df1 << 63));
+            const uint64_t s2 = s1 & ~((df0 >> 2) | (df1 << 62));
+            const uint64_t s3 = s2 & ~((df0 >> 3) | (df1 << 61));
             const uint32_t term = hi32(x0) >> rb.term_sh;
             const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
             const uint32_t slot = base[shr_lo32(x0, shift) & mask] + p;
-            bool head = valid & ((v[j] >> 31) != 0u);
+            uint64_t hm = df0 & vm;  // heads
             // the first row of a run that may have begun before the tile
-            const bool c0 = head & cut_equal(x0, first);
-            if (n_tail != 0u && __ballot(c0) != 0ull) {
-                if (c0)
-                    for (uint32_t i = 0; i < n_tail; ++i)
-                        if (!key_differs(rb, ps->nbr[i], x0)) head = false;
+#ifndef SEBM25_EXP_NONBR
+            if (n_tail != 0u) {
+                const uint64_t c0m = hm & ballot(cut_equal(x0, first));
+                if (c0m != 0ull) {
+                    bool cont = false;
+                    if (lanes(c0m))
+                        for (uint32_t i = 0; i < n_tail; ++i)
+                            if (!key_differs(rb, ps->nbr[i], x0)) cont = true;
+                    hm &= ~ballot(cont);
+                }
             }
-            const bool webhead = head & !news[j];
-            const bool kept = head & (news[j] | ((shr_lo32(x0, rb.fc_sh) & 3u) != 3u));
-            const uint64_t km = __ballot(kept), wm = __ballot(webhead);
-            const bool same1 = !(n1 >> 31), same2 = same1 & !(n2 >> 31), same3 = same2 & !(n3 >> 31);
-            uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
-            uint32_t run_rows = 1u + (same1 ? 1u : 0u) + (same2 ? 1u : 0u) + (same3 ? 1u : 0u);
-            // a run that may go on behind the tile
-            const bool c1 = kept & cut_equal(x0, last);
-            if (n_ahead != 0u && __ballot(c1) != 0ull) {
-                if (c1)
-                    for (uint32_t i = 0; i < n_ahead; ++i) {
-                        const uint64_t y = ps->nbr[POST_NBR + i];
-                        if (!key_differs(rb, y, x0)) {
-                            w += tenths24(rb, y, news[j]);
-                            ++run_rows;
+#endif
+            // field code 3 marks the rows of a web doc whose status is not 'done' (set by the first sort pass)
+            const uint64_t km = hm & (nm0 | ballot((shr_lo32(x0, rb.fc_sh) & 3u) != 3u));  // kept: the slot gets a weight
+            const uint64_t wm = hm & ~nm0;                                                  // web heads
+            uint32_t w = t0w + (lanes(s1) ? n1 : 0u) + (lanes(s2) ? n2 : 0u);
+            fix_m |= km & s3;  // more than three rows in one run: left to the exact pass
+            // a run that may go on behind the tile: the rows there add to its weight, and count as merged rows
+#ifndef SEBM25_EXP_NONBR
+            if (n_ahead != 0u) {
+                const uint64_t c1m = hm & ballot(cut_equal(x0, last));
+                if (c1m != 0ull) {
+                    const bool nwj = lanes(nm0);
+                    const uint32_t here = 1u + (lanes(s1) ? 1u : 0u) + (lanes(s2) ? 1u : 0u);
+                    uint32_t more = 0;
+                    if (lanes(c1m))
+                        for (uint32_t i = 0; i < n_ahead; ++i) {
+                            const uint64_t y = ps->nbr[POST_NBR + i];
+                            if (!key_differs(rb, y, x0)) {
+                                w += tenths24(rb, y, nwj);
+                                ++more;
+                            }
                         }
-                    }
+                    fix_m |= km & ballot(here + more > 3u);
+                    if (lanes(wm) && more != 0u) atomicAdd(&po.dup[term], more);
+                }
             }
-            if (__ballot(kept & (run_rows > 3u)) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
-            if (valid) {
+#endif
+            if (lanes(vm)) {
+#ifndef SEBM25_EXP_ONESTORE
                 po.post_unit[slot] = unit;
-                po.post_w[slot] = kept ? w : POST_HOLE;
+#endif
+                po.post_w[slot] = lanes(km) ? w : POST_HOLE;
             }
-            if (__ballot(kept & (w >= 0xFFFFu)) && lane == 0) atomicOr(err, DEV_BIG_WEIGHT);
-            if (valid & news[j] & ts_new[j]) atomicMin(&po.news_ptr[term], slot);
+            // weights of 0xFFFF tenths and more do not fit the 16-bit accumulator fields of the stepwise scoring kernels
+            big_m |= km & ballot(w >= 0xFFFFu);
             n_kept += (uint32_t)__popcll(km);
             n_wh += (uint32_t)__popcll(wm);
             n_kept_web += (uint32_t)__popcll(km & wm);
+            // the first news row of a term in this tile: candidate for the term's first news slot
+            const uint64_t nvm = nm0 & vm;
+            if (nvm != 0ull) {
+                const uint32_t dh = hi32(x0) ^ lane_up1_edge(hi32(x0), hi32(bef));
+                const uint32_t dl = lo32(x0) ^ lane_up1_edge(lo32(x0), lo32(bef));
+                if (lanes(nvm & ballot(((dh & ts_hi) | (dl & ts_lo)) != 0u))) atomicMin(&po.news_ptr[term], slot);
+            }
 
-            // web rows that are not heads, per term: rounds of one term only extend a running count
-            const uint64_t dm = __ballot(valid & !news[j] & !head);
-            if (dm != 0ull) {
-                const uint64_t starts = (__ballot(term_new[j]) | 1ull) & vm;
-                if (starts == 1ull) {
-                    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
-                    if (t0 != run_term) {
-                        if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
-                        run_term = t0;
-                        run_cnt = 0;
-                    }
-                    run_cnt += (uint32_t)__popcll(dm);
-                } else {
+            // Web rows that are not the head of their run, per term: every web head brings the rows that continue
+            // its run (one or two; longer runs go to the exact pass).  Rounds of one term only extend a running
+            // count; in a round of several terms the first segment ends the running count, the last one starts
+            // the next, and the terms in between (short lists) add per head.
+#ifndef SEBM25_EXP_NODUP
+            const uint64_t d1 = wm & s1, d2 = wm & s2;
+            if (d1 != 0ull) {
+                const uint32_t term_bef = hi32(bef) >> rb.term_sh;
+                const uint64_t starts = (ballot(term != lane_up1_edge(term, term_bef)) | 1ull) & vm;
+                const uint32_t tf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
+                if (tf0 != run_term) {
                     if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
-                    run_term = NO_TERM;
+                    run_term = tf0;
                     run_cnt = 0;
-                    const uint64_t ends = vm & ((starts >> 1) | ~(vm >> 1));  // the last lane of every term segment
-                    if ((ends >> lane) & 1ull) {
-                        const uint64_t upto = lt | (1ull << lane);
-                        const int s0 = 63 - __clzll((long long)(starts & upto));
-                        const uint32_t cnt = (uint32_t)__popcll(dm & upto & ~((1ull << s0) - 1ull));
-                        if (cnt) atomicAdd(&po.dup[term], cnt);
+                }
+                if (starts == 1ull) {
+                    run_cnt += (uint32_t)__popcll(d1) + (uint32_t)__popcll(d2);
+                } else {
+                    const uint64_t rest = starts & ~1ull;
+                    const uint64_t seg_first = (1ull << (__ffsll((unsigned long long)rest) - 1)) - 1ull;
+                    const int last_start = 63 - __clzll((long long)rest);
+                    const uint64_t seg_last = ~((1ull << last_start) - 1ull);
+                    run_cnt += (uint32_t)__popcll(d1 & seg_first) + (uint32_t)__popcll(d2 & seg_first);
+                    if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
+                    run_term = (uint32_t)__builtin_amdgcn_readlane((int)term, last_start);
+                    run_cnt = (uint32_t)__popcll(d1 & seg_last) + (uint32_t)__popcll(d2 & seg_last);
+                    const uint64_t mid = d1 & ~seg_first & ~seg_last;
+                    if (mid != 0ull) {
+                        if (lanes(mid)) atomicAdd(&po.dup[term], lanes(d2) ? 2u : 1u);
                     }
                 }
             }
+#endif
+            x0 = x1; bef = bef1; t0w = t1w; df0 = df1; nm0 = nm1;
         }
+        if (check_big) fix_m |= ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u);
         if (lane == 0) {
             if (run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
+            if (fix_m) atomicOr(err, DEV_NEED_FIXUP);
+            if (big_m) atomicOr(err, DEV_BIG_WEIGHT);
             atomicAdd(&ps->tot[0], n_kept);
             atomicAdd(&ps->tot[1], n_wh);
             atomicAdd(&ps->tot[2], n_kept_web);
