@@ -53,6 +53,17 @@ __device__ __forceinline__ uint32_t lane_up1_edge(uint32_t x, uint32_t edge) {
 __device__ __forceinline__ uint32_t lane_dn1_edge(uint32_t x, uint32_t edge) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
+// lane i <- lane i-1 of x, lane 0 <- lane 63 of prev: a rotation of prev puts its last lane into lane 0, the shift
+// of x then fills every other lane (two DPP moves, no trip through a scalar register)
+__device__ __forceinline__ uint32_t lane_up1_from(uint32_t x, uint32_t prev) {
+    const int t = __builtin_amdgcn_update_dpp(0, (int)prev, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+// lane i <- lane i+1 of x, lane 63 <- lane 0 of next
+__device__ __forceinline__ uint32_t lane_dn1_from(uint32_t x, uint32_t next) {
+    const int t = __builtin_amdgcn_update_dpp(0, (int)next, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
 template <int L>
 __device__ __forceinline__ uint64_t lane_bcast(uint64_t x) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), L) << 32) |
@@ -356,11 +367,13 @@ static_assert(sizeof(PostTileShared) <= SORT_WAVES * SORT_MAX_BINS * 2, "fits th
 // host then sorts the rows out and runs k_postings over them.
 // df is not counted here: a term's web heads are its web rows minus the web rows that are not heads, and only
 // the latter (about 3 % of the rows of a crawled corpus) cost an atomic.
-__device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t* base, PostTileShared* ps, uint32_t n_tile,
+template <bool LOWKEY>
+__device__ __forceinline__ void post_tile(uint64_t* rows_s, const uint32_t* base, PostTileShared* ps, uint32_t n_tile,
                                           uint64_t tile0, uint64_t end, uint64_t R, uint32_t chunk, int shift, uint32_t mask,
                                           const RowFmt& fmt, uint64_t nbr, uint64_t edge_row, uint64_t row0, uint32_t* err,
                                           const PostOut& po) {
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    // the wave index is the same for all lanes: tell the compiler, so that everything derived from it stays scalar
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
     const RowBits rb(fmt);
     const uint64_t cut = (~0ull << fmt.key_shift()) & ~((uint64_t)mask << shift);  // key bits below this pass's digit
     const uint32_t cut_hi = hi32(cut), cut_lo = lo32(cut);
@@ -388,6 +401,11 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
             if (n == POST_NBR) atomicOr(err, DEV_NEED_FIXUP);
         }
     }
+    if (n_tile < (uint32_t)SORT_TILE) {
+        // a partial tile: what follows its last row in the tile buffer reads as a row of another unit
+        const uint64_t sent = rows_s[n_tile - 1u] ^ (1ull << fmt.key_shift());
+        for (uint32_t q = n_tile + threadIdx.x; q < (uint32_t)SORT_TILE; q += SORT_THREADS) rows_s[q] = sent;
+    }
     __syncthreads();
     const uint32_t n_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps->n_tail);
     const uint32_t n_ahead = (uint32_t)__builtin_amdgcn_readfirstlane((int)ps->n_ahead);
@@ -400,59 +418,70 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
         // per-lane condition.
         auto ballot = [](bool c) { return (uint64_t)__builtin_amdgcn_ballot_w64(c); };
         auto lanes = [](uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
-        // a row behind the tile reads as a row of another unit, the row before it as one of another term
-        const uint64_t sent = rows_s[n_tile - 1u] ^ (1ull << fmt.key_shift());
-        auto row_at = [&](uint32_t p) {
-            const uint64_t r = rows_s[min(p, n_tile - 1u)];
-            return p < n_tile ? r : sent;
-        };
         const uint32_t ts_hi = rb.term_hi | rb.src_hi, ts_lo = rb.src_lo;
         const bool check_big = (rb.big_hi | rb.big_lo) != 0u;  // tf can reach 2^24 at all
+        const int dsh = shift - 32;                              // this pass's digit lies in the high word
         uint32_t seen_hi = 0, seen_lo = 0;
         // One round ahead of the round being written: per row its own weight in tenths, per round the rows whose key
-        // differs from the row before (df) and the news rows (nm).  Round 8 is the first rows behind the wave's
-        // (lanes 0..2 are looked at).
-        auto stage = [&](uint64_t xx, uint64_t bef, uint32_t& t10, uint64_t& df, uint64_t& nmask) {
-            const uint32_t dh = hi32(xx) ^ lane_up1_edge(hi32(xx), hi32(bef));
-            const uint32_t dl = lo32(xx) ^ lane_up1_edge(lo32(xx), lo32(bef));
-            const bool nw = is_news(rb, xx);
-            df = ballot(((dh & rb.key_hi) | (dl & rb.key_lo)) != 0u);
+        // differs from the row before (df), the news rows (nm) and the rows of web docs that are 'done' (ok: field
+        // code 3 marks the others, set by the first sort pass).  xp: the round before (its last lane precedes lane 0).
+        auto stage = [&](uint64_t xx, uint64_t xp, uint32_t& t10, uint64_t& df, uint64_t& nmask, uint64_t& ok) {
+            const uint32_t dh = hi32(xx) ^ lane_up1_from(hi32(xx), hi32(xp));
+            const uint32_t dl = lo32(xx) ^ lane_up1_from(lo32(xx), lo32(xp));
+            const bool nw = (hi32(xx) & rb.src_hi) != 0u;  // at most 2^20 terms here: the source bit is in the high word
+            df = ballot((LOWKEY ? (dl & rb.key_lo) | dh : dh & rb.key_hi) != 0u);
             nmask = ballot(nw);
-            t10 = tenths24(rb, xx, nw);
+            // the field code times 8: selects the multiplier's byte of 0x0A11200A (10, 32, 17, 10) and tells rows of docs not done
+            const uint32_t fc8 = (LOWKEY ? lo32(xx) >> (rb.fc_sh - 3) : shr_lo32(xx, rb.fc_sh - 3)) & 0x18u;
+            ok = ballot(fc8 != 0x18u);
+            const uint32_t mult = nw ? 10u : __builtin_amdgcn_ubfe(0x0A11200Au, fc8, 8u);
+            t10 = __umul24(lo32(xx) & rb.tf24_mask, mult);
             if (check_big) {
                 seen_hi |= hi32(xx);
                 seen_lo |= lo32(xx);
             }
         };
-        uint64_t x0 = row_at(wb + lane);
-        uint64_t bef = wave ? rows_s[wb - 1u] : rows_s[0] ^ (1ull << 63);
+        // rows behind the tile read as rows of another unit, the row before the tile as one of another term
+        const uint64_t sent = rows_s[n_tile - 1u] ^ (1ull << fmt.key_shift());
+        const bool last_wave = wave == SORT_WAVES - 1u;
+        uint64_t x0 = rows_s[wb + lane];
+        uint64_t xp = wave ? rows_s[wb - 1u] : rows_s[0] ^ (1ull << 63);  // every lane: the row before the wave's first
         uint32_t t0w = 0;
-        uint64_t df0 = 0, nm0 = 0;
-        stage(x0, bef, t0w, df0, nm0);
+        uint64_t df0 = 0, nm0 = 0, ok0 = 0;
+        stage(x0, xp, t0w, df0, nm0, ok0);
         uint64_t fix_m = 0, big_m = 0;
+        const int rows_here = (int)(n_tile - wb);  // rows of the tile from this wave's first on
 
         constexpr uint32_t NO_TERM = 0xFFFFFFFFu;
         uint32_t run_term = NO_TERM, run_cnt = 0;  // web rows that are no heads, of the term the last rounds ended with
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const uint32_t p = wb + (uint32_t)j * 64u + lane;
-            const uint64_t x1 = row_at(wb + (uint32_t)(j + 1) * 64u + (j + 1 < SORT_ITEMS ? lane : (lane & 3u)));
-            const uint64_t bef1 = lane_bcast<63>(x0);
+            // the next round (the last wave's ninth would lie behind the tile buffer)
+            uint64_t x1;
+            if (j + 1 < SORT_ITEMS) {
+                x1 = rows_s[wb + (uint32_t)(j + 1) * 64u + lane];
+            } else {
+                x1 = rows_s[min(wb + (uint32_t)SORT_ITEMS * 64u + (lane & 3u), (uint32_t)SORT_TILE - 1u)];
+                if (last_wave) x1 = sent;
+            }
             uint32_t t1w = 0;
-            uint64_t df1 = 0, nm1 = 0;
-            stage(x1, bef1, t1w, df1, nm1);
+            uint64_t df1 = 0, nm1 = 0, ok1 = 0;
+            stage(x1, x0, t1w, df1, nm1, ok1);
 
-            const uint64_t vm = ballot(p < n_tile);
+            const int left = rows_here - j * 64;
+            const uint64_t vm = left >= 64 ? ~0ull : left <= 0 ? 0ull : (1ull << left) - 1ull;
             // weights of the next two rows: lane shifts; at the wave edge the first lanes of the next round
-            const uint32_t n1 = lane_dn1_edge(t0w, (uint32_t)__builtin_amdgcn_readlane((int)t1w, 0));
+            const uint32_t n1 = lane_dn1_from(t0w, t1w);
             const uint32_t n2 = lane_dn1_edge(n1, (uint32_t)__builtin_amdgcn_readlane((int)t1w, 1));
             // rows whose next one / two / three rows continue their run
             const uint64_t s1 = ~((df0 >> 1) | (df1 << 63));
             const uint64_t s2 = s1 & ~((df0 >> 2) | (df1 << 62));
             const uint64_t s3 = s2 & ~((df0 >> 3) | (df1 << 61));
             const uint32_t term = hi32(x0) >> rb.term_sh;
-            const uint32_t unit = shr_lo32(x0, rb.unit_sh) & rb.unit_mask;
-            const uint32_t slot = base[shr_lo32(x0, shift) & mask] + p;
+            const uint32_t unit = LOWKEY ? __builtin_amdgcn_alignbit(hi32(x0), lo32(x0), (uint32_t)rb.unit_sh) & rb.unit_mask
+                                         : (hi32(x0) >> (rb.unit_sh - 32)) & rb.unit_mask;
+            const uint32_t slot = base[(hi32(x0) >> dsh) & mask] + p;
             uint64_t hm = df0 & vm;  // heads
             // the first row of a run that may have begun before the tile
 #ifndef SEBM25_EXP_NONBR
@@ -461,15 +490,15 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
                 if (c0m != 0ull) {
                     bool cont = false;
                     if (lanes(c0m))
+#pragma unroll 1
                         for (uint32_t i = 0; i < n_tail; ++i)
                             if (!key_differs(rb, ps->nbr[i], x0)) cont = true;
                     hm &= ~ballot(cont);
                 }
             }
 #endif
-            // field code 3 marks the rows of a web doc whose status is not 'done' (set by the first sort pass)
-            const uint64_t km = hm & (nm0 | ballot((shr_lo32(x0, rb.fc_sh) & 3u) != 3u));  // kept: the slot gets a weight
-            const uint64_t wm = hm & ~nm0;                                                  // web heads
+            const uint64_t km = hm & (nm0 | ok0);  // kept: the slot gets a weight
+            const uint64_t wm = hm & ~nm0;         // web heads
             uint32_t w = t0w + (lanes(s1) ? n1 : 0u) + (lanes(s2) ? n2 : 0u);
             fix_m |= km & s3;  // more than three rows in one run: left to the exact pass
             // a run that may go on behind the tile: the rows there add to its weight, and count as merged rows
@@ -481,6 +510,7 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
                     const uint32_t here = 1u + (lanes(s1) ? 1u : 0u) + (lanes(s2) ? 1u : 0u);
                     uint32_t more = 0;
                     if (lanes(c1m))
+#pragma unroll 1
                         for (uint32_t i = 0; i < n_ahead; ++i) {
                             const uint64_t y = ps->nbr[POST_NBR + i];
                             if (!key_differs(rb, y, x0)) {
@@ -507,36 +537,33 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
             // the first news row of a term in this tile: candidate for the term's first news slot
             const uint64_t nvm = nm0 & vm;
             if (nvm != 0ull) {
-                const uint32_t dh = hi32(x0) ^ lane_up1_edge(hi32(x0), hi32(bef));
-                const uint32_t dl = lo32(x0) ^ lane_up1_edge(lo32(x0), lo32(bef));
+                const uint32_t dh = hi32(x0) ^ lane_up1_from(hi32(x0), hi32(xp));
+                const uint32_t dl = lo32(x0) ^ lane_up1_from(lo32(x0), lo32(xp));
                 if (lanes(nvm & ballot(((dh & ts_hi) | (dl & ts_lo)) != 0u))) atomicMin(&po.news_ptr[term], slot);
             }
 
             // Web rows that are not the head of their run, per term: every web head brings the rows that continue
-            // its run (one or two; longer runs go to the exact pass).  Rounds of one term only extend a running
-            // count; in a round of several terms the first segment ends the running count, the last one starts
-            // the next, and the terms in between (short lists) add per head.
+            // its run (one or two; longer runs go to the exact pass).  The tile is ordered by term, so a round whose
+            // first and last row agree in it is a round of one term and only extends a running count; in a round of
+            // several terms the first term's rows end the running count, the last term's start the next, and the
+            // terms in between (short lists) add per head.
+            const uint32_t t_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
+            const uint32_t t_last = (uint32_t)__builtin_amdgcn_readlane((int)term, left >= 64 ? 63 : left > 0 ? left - 1 : 0);
 #ifndef SEBM25_EXP_NODUP
             const uint64_t d1 = wm & s1, d2 = wm & s2;
             if (d1 != 0ull) {
-                const uint32_t term_bef = hi32(bef) >> rb.term_sh;
-                const uint64_t starts = (ballot(term != lane_up1_edge(term, term_bef)) | 1ull) & vm;
-                const uint32_t tf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)term);
-                if (tf0 != run_term) {
+                if (t_first != run_term) {
                     if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
-                    run_term = tf0;
+                    run_term = t_first;
                     run_cnt = 0;
                 }
-                if (starts == 1ull) {
+                if (t_first == t_last) {
                     run_cnt += (uint32_t)__popcll(d1) + (uint32_t)__popcll(d2);
                 } else {
-                    const uint64_t rest = starts & ~1ull;
-                    const uint64_t seg_first = (1ull << (__ffsll((unsigned long long)rest) - 1)) - 1ull;
-                    const int last_start = 63 - __clzll((long long)rest);
-                    const uint64_t seg_last = ~((1ull << last_start) - 1ull);
+                    const uint64_t seg_first = ballot(term == t_first), seg_last = ballot(term == t_last);
                     run_cnt += (uint32_t)__popcll(d1 & seg_first) + (uint32_t)__popcll(d2 & seg_first);
                     if (lane == 0 && run_cnt) atomicAdd(&po.dup[run_term], run_cnt);
-                    run_term = (uint32_t)__builtin_amdgcn_readlane((int)term, last_start);
+                    run_term = t_last;
                     run_cnt = (uint32_t)__popcll(d1 & seg_last) + (uint32_t)__popcll(d2 & seg_last);
                     const uint64_t mid = d1 & ~seg_first & ~seg_last;
                     if (mid != 0ull) {
@@ -545,7 +572,7 @@ __device__ __forceinline__ void post_tile(const uint64_t* rows_s, const uint32_t
                 }
             }
 #endif
-            x0 = x1; bef = bef1; t0w = t1w; df0 = df1; nm0 = nm1;
+            xp = x0; x0 = x1; t0w = t1w; df0 = df1; nm0 = nm1; ok0 = ok1;
         }
         if (check_big) fix_m |= ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u);
         if (lane == 0) {
@@ -600,6 +627,8 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     const uint32_t nb = 1u << bits, mask = nb - 1u;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t t = threadIdx.x;
+    // the last pass of a sort on the term bits takes its digit from the high word alone (term ids are 32-bit)
+    auto digit_of = [&](uint64_t r) { return POST ? (hi32(r) >> (shift - 32)) & mask : shr_lo32(r, shift) & mask; };
     // workgroups b, b + 8, b + 16 ... run on one XCD: give them consecutive chunks, so that the runs
     // they append to a digit bin at about the same time are neighbours in that XCD's L2
     const uint32_t per_xcd = (G + 7u) / 8u;
@@ -778,7 +807,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
 #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const bool valid = l0 + (uint32_t)j * 64u < n_tile;
-            const uint32_t d = shr_lo32(row[j], shift) & mask;
+            const uint32_t d = digit_of(row[j]);
             dg[j] = d;
             const uint64_t vm = __ballot(valid);
             // the group of the first valid lane (the hot digit of skewed or sorted rows) by one compare
@@ -870,7 +899,7 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
         if (l0 + (uint32_t)j * 64u < n_tile) {
-            const uint32_t d = shr_lo32(row[j], shift) & mask;
+            const uint32_t d = digit_of(row[j]);
             rows_s[whist[wave][d] + rk[j]] = row[j];
         }
     }
@@ -888,8 +917,13 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             }
         }
     } else {
-        post_tile(rows_s, base, reinterpret_cast<PostTileShared*>(&whist[0][0]), n_tile, tile0, end, R, chunk, shift, mask, fmt,
-                  nbr, edge_row, row[0], ctx.err, po);
+        // unit ids reach into the low word of the row (large id spaces: the usual case) or lie in the high word
+        if (fmt.key_shift() < 32)
+            post_tile<true>(rows_s, base, reinterpret_cast<PostTileShared*>(&whist[0][0]), n_tile, tile0, end, R, chunk, shift, mask,
+                            fmt, nbr, edge_row, row[0], ctx.err, po);
+        else
+            post_tile<false>(rows_s, base, reinterpret_cast<PostTileShared*>(&whist[0][0]), n_tile, tile0, end, R, chunk, shift, mask,
+                             fmt, nbr, edge_row, row[0], ctx.err, po);
     }
 }
 
