@@ -2,7 +2,7 @@
 """Benchmark of the BM25 index-build path and the batched top-k scoring path on MI355X.
 
 One "step" = one full statistics job over this rank's shard of the synthetic Zipfian corpus, rows
-already resident in HBM: radix sort -> sorted rows into posting slots -> df / document totals ->
+already resident in HBM: radix sort whose last pass writes the posting slots -> df / document totals ->
 (N > 1: one all-reduce of df[V] and the document totals over RCCL) -> idf.  The headline runs the
 variant the drop-in runs: `doc_flags` supplied (every doc 'done'); scoring breaks ties on the unit id, as an index
 does whose docs the export numbered in url order (explicit rank arrays are timed as a variant).
@@ -34,7 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-PROFILE_TAG = "r2"
+PROFILE_TAG = "r3"
 
 
 def parse():
@@ -293,9 +293,10 @@ def main():
     # algorithmic bytes per input row of each build kernel (what it must read + what it must write)
     KERNELS = {
         "sort_hist_0": ("k_sort_hist<0>", 4), "sort_hist_1": ("k_sort_hist<2>", 8),
-        "sort_scatter_0": ("k_sort_scatter_tile<0>", 13 + 8),   # raw row in, packed row out
-        "sort_scatter_1": ("k_sort_scatter_tile<2>", 8 + 8),    # packed row in, packed row out
-        "postings": ("k_postings", 8 + 8),                      # packed row in, posting slot out
+        "sort_scatter_0": ("k_sort_scatter_tile<0, false>", 13 + 8),  # raw row in, packed row out
+        "sort_scatter_1": ("k_sort_scatter_tile<2, false>", 8 + 8),   # packed row in, packed row out
+        "scatter_postings": ("k_sort_scatter_tile<2, true>", 8 + 8),  # packed row in, posting slot out (the last pass)
+        "postings": ("k_postings", 8 + 8),                            # packed row in, posting slot out (separate pass)
     }
     traffic_db = load_traffic()
     build_traffic = traffic_db.get("build", {}) if traffic_db.get("build", {}).get("rows") == int(info.n_rows) else {}

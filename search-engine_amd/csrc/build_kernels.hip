@@ -737,15 +737,17 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             for (int j = 0; j < SORT_ITEMS; ++j) dfl[j] = SEBM25_DOC_DONE;
         }
         uint32_t carry_u = lo32(carry), carry_s = hi32(carry);
+        auto ballot = [](bool c) { return (uint64_t)__builtin_amdgcn_ballot_w64(c); };
     #pragma unroll
         for (int j = 0; j < SORT_ITEMS; ++j) {
             const uint32_t st = m[j] & 3u, field = m[j] >> 2;
             const bool news = st == SEBM25_SRC_NEWS;
             // bitwise, not short-circuit: four compares and mask logic instead of nested branches
-            const bool bad = (term[j] >= ctx.n_terms) | (st - 1u >= 2u) |
-                             (unit[j] >= (news ? ctx.n_articles : ctx.n_docs)) |
-                             (check_tf & ((tfv[j] >> tf_sh) != 0u));
-            if (__ballot(bad) != 0ull) {  // one scalar branch per round on the good path
+            const bool bad_t = term[j] >= ctx.n_terms, bad_s = st - 1u >= 2u, bad_u = unit[j] >= (news ? ctx.n_articles : ctx.n_docs),
+                       bad_f = check_tf & ((tfv[j] >> tf_sh) != 0u);
+            const bool bad = bad_t | bad_s | bad_u | bad_f;
+            // masks of plain compares, combined in scalar registers
+            if ((ballot(bad_t) | ballot(bad_s) | ballot(bad_u) | ballot(bad_f)) != 0ull) {  // one scalar branch per round on the good path
                 if (bad) {
                     atomicOr(ctx.err, DEV_ERR_RANGE);
                     // the same key bits as the histogram saw, every later index in range
@@ -765,16 +767,16 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
             const uint32_t prev_u = lane_up1_edge(unit[j], carry_u), prev_s = lane_up1_edge(s, carry_s);
             carry_u = (uint32_t)__builtin_amdgcn_readlane((int)unit[j], 63);
             carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-            const bool same = (unit[j] == prev_u) & (s == prev_s);
-            const bool less = (s < prev_s) | ((s == prev_s) & (unit[j] < prev_u));
-            if (ctx.check_order && __ballot(less) != 0ull) {
+            const uint64_t eq_s = ballot(s == prev_s), same_m = ballot(unit[j] == prev_u) & eq_s;
+            const uint64_t less_m = ballot(s < prev_s) | (eq_s & ballot(unit[j] < prev_u));
+            if (ctx.check_order && less_m != 0ull) {
                 if (lane == 0) atomicOr(ctx.err, DEV_ERR_ORDER);
             }
             // body length of web docs: sum of tf over field-4 rows.  A round usually lies inside
             // one doc (every lane but the first has its predecessor's key): then one lane adds the
             // wave's sum to the tile's LDS counter of that doc.
             const uint32_t body = (!news & (field == SEBM25_FIELD_BODY) & (unit[j] < ctx.n_docs)) ? tfv[j] : 0u;
-            const bool uniform = (__ballot(!same) & ~1ull) == 0ull;
+            const bool uniform = (~same_m & ~1ull) == 0ull;
             uint32_t add = body;
             bool do_add = body != 0u;
             if (uniform) {
