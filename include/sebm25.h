@@ -228,8 +228,10 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
  *      :351-352 (SEARCH_SQL :13-40, FALLBACK_SEARCH_SQL :42-66, NEWS_SEARCH_SQL :68-101) ------ */
 
 /*
- * Batched scoring.  Query q has term ids q_terms[q_offsets[q] .. q_offsets[q+1]) (host arrays);
- * duplicate ids count once and ids >= n_terms match nothing (`t.term = ANY($1)`).
+ * Batched scoring.  Query q has term ids q_terms[q_offsets[q] .. q_offsets[q+1]) (host arrays), any number
+ * of them; duplicate ids count once and ids >= n_terms match nothing (`t.term = ANY($1)`).  Queries of up to
+ * eight distinct matching terms take the fastest kernels, up to 256 the general one, and beyond that the
+ * general one with its list cursors in device memory (8 bytes per term and work item, allocated by the call).
  * For each unit with at least one matching posting of the requested source:
  *   score   = sum over query terms (in the order given) of (idf_used[t] / 10) * w10(t, unit)
  *             with w10 the integer weight in tenths; double arithmetic, no fused multiply-add
@@ -251,8 +253,8 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
  * items, the deduplicated query terms and the temporary result lists of queries that are split by
  * unit range live in one fixed device array of about 2.8 MB per GPU (held from sebm25_create of the
  * first handle on that GPU until the process ends), and the host-side plan in pinned storage of the
- * handle.  Limits: n_queries <= 1024, k <= 256, at most 4096 distinct matching query terms per call
- * (SEBM25_E_RANGE beyond them); all output arrays must be device memory (out_tie may be NULL).  A
+ * handle.  Limits: n_queries <= 1024, k <= 256, at most 4096 distinct matching query terms per call and 256
+ * per query (SEBM25_E_RANGE beyond them); all output arrays must be device memory (out_tie may be NULL).  A
  * batch whose split queries would need more than 131072 temporary entries (lists x k) or more than
  * 4096 work items is scored without splitting, which changes the speed and never the result.  All
  * calls on one GPU share that GPU's array: within a process they are serialised by the library;

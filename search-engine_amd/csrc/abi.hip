@@ -2,6 +2,7 @@
 // the build / search pipelines as sequences of kernel launches, and result copies.
 #include <algorithm>
 #include <thread>
+#include <unordered_set>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -16,7 +17,7 @@ namespace {
 thread_local std::string g_thread_err;
 
 constexpr uint32_t MAX_K = 2048;
-constexpr uint32_t MAX_QUERY_TERMS = 255;  // the matched-terms count of a result is kept in 8 bits
+constexpr uint32_t MAX_QUERY_TERMS = 0xFFFFFFFFu;  // sebm25_search: no limit of its own (a query holds at most n_terms distinct terms)
 constexpr uint32_t RED_MAX_CHUNKS = 16384;  // wavefronts
 }  // namespace
 
@@ -27,7 +28,7 @@ struct H2DJob {
 };
 
 struct SearchPlanVecs {
-    std::vector<uint32_t> flat, q_toff, q_nt, q_ns, first, nlists, bucket;
+    std::vector<uint32_t> flat, q_toff, q_nt, q_order, q_ns, first, nlists, bucket;
     std::vector<uint64_t> q_len, item_len;
     std::vector<QItem> items, unsorted;
 };
@@ -91,7 +92,7 @@ struct sebm25_index {
     NaHost* na_host = nullptr;   // host plan storage of sebm25_search_noalloc (pinned, fixed size)
 
     // search scratch
-    DevBuf q_items, q_terms, q_first, q_n;
+    DevBuf q_items, q_terms, q_first, q_n, q_wide;
     DevBuf o_unit, o_score, o_mat, o_tie, o_count, t_unit, t_score, t_mat, t_tie, t_count;
     DevBuf o_pack;                 // small host-bound results: all five arrays in one buffer, one copy back
     void* o_host = nullptr;        // its pinned host twin (grow-only)
@@ -158,7 +159,7 @@ std::mutex g_na_device_mu[NA_MAX_DEVICES];  // calls on one GPU share its array:
 // host-side plan storage of the no-alloc entry point, allocated once per handle by sebm25_create
 struct NaHost {
     uint32_t flat[NA_MAX_TERMS];
-    uint32_t q_toff[NA_MAX_QUERIES], q_nt[NA_MAX_QUERIES], q_ns[NA_MAX_QUERIES], first[NA_MAX_QUERIES], nlists[NA_MAX_QUERIES];
+    uint32_t q_toff[NA_MAX_QUERIES], q_nt[NA_MAX_QUERIES], q_order[NA_MAX_QUERIES], q_ns[NA_MAX_QUERIES], first[NA_MAX_QUERIES], nlists[NA_MAX_QUERIES];
     uint64_t q_len[NA_MAX_QUERIES];
     QItem items[NA_MAX_ITEMS], unsorted[NA_MAX_ITEMS];
     uint64_t item_len[NA_MAX_ITEMS];
@@ -1163,7 +1164,7 @@ void sebm25_destroy(sebm25_index* ix) {
                          &ix->df_local, &ix->df_global, &ix->term_rows, &ix->idf, &ix->idf_used,
                          &ix->doc_len, &ix->scalars, &ix->st_term, &ix->st_unit, &ix->st_tf, &ix->st_meta, &ix->st_wc,
                          &ix->st_flags, &ix->st_misc, &ix->url_rank_web, &ix->url_rank_news, &ix->q_items, &ix->q_terms,
-                         &ix->q_first, &ix->q_n, &ix->o_pack, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
+                         &ix->q_first, &ix->q_n, &ix->q_wide, &ix->o_pack, &ix->o_unit, &ix->o_score, &ix->o_mat, &ix->o_tie, &ix->o_count, &ix->t_unit,
                          &ix->t_score, &ix->t_mat, &ix->t_tie, &ix->t_count, &ix->m_in[0], &ix->m_in[1], &ix->m_in[2],
                          &ix->m_in[3], &ix->m_in[4], &ix->gen_rows, &ix->gen_cdf};
         for (DevBuf* b : all) b->release();
@@ -1481,7 +1482,7 @@ namespace {
 struct PlanStore {
     uint32_t* flat;      // [flat_cap] deduped, matching terms of all queries
     size_t flat_cap;
-    uint32_t *q_toff, *q_nt, *q_ns;  // [n_queries] offset into flat, number of terms, number of unit ranges
+    uint32_t *q_toff, *q_nt, *q_order, *q_ns;  // [n_queries] offset into flat, number of terms, list order (stepwise kernels), number of unit ranges
     uint64_t* q_len;                 // [n_queries] postings of the query
     uint32_t *first, *nlists;        // [n_queries] temporary lists of a split query (nlists 0: not split)
     QItem* items;                    // [item_cap] sorted work items (pass 2)
@@ -1492,6 +1493,7 @@ struct PlanStore {
 };
 struct PlanInfo {
     uint32_t n_flat = 0, n_items = 0, n_tmp = 0;
+    uint64_t n_wide_words = 0;  // cursor storage of the items with more than SCORE_REG_LISTS lists
     uint32_t n_by_t[SCORE_FAST_T + 1] = {};
 };
 size_t plan_buckets() { return (size_t)(score_fast_max_terms() + 1) * PLAN_PER_GROUP; }
@@ -1499,7 +1501,7 @@ size_t plan_buckets() { return (size_t)(score_fast_max_terms() + 1) * PLAN_PER_G
 // max_tmp_entries: capacity of the temporary slice lists in entries (lists x k); a plan that would
 // need more is made without splitting.  Returns 0 or an error code (message set).
 int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint64_t* q_offsets, uint32_t n_queries,
-               uint32_t k, PlanStore& st, PlanInfo& info, uint64_t max_tmp_entries) {
+               uint32_t k, PlanStore& st, PlanInfo& info, uint64_t max_tmp_entries, uint32_t max_query_terms = MAX_QUERY_TERMS) {
     const uint32_t n_units = news ? ix->n_articles : ix->n_docs;
     const uint32_t* lens = ix->h_list_len.data() + (news ? 1 : 0);
     auto list_len = [&](uint32_t t) -> uint64_t { return lens[2 * (size_t)t]; };
@@ -1510,6 +1512,8 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
     // few queries ahead while this query is planned
     const uint64_t n_q_terms = q_offsets[n_queries];
     constexpr uint64_t AHEAD = 24;
+    std::unordered_set<uint32_t> seen;   // only touched by queries of 64 and more distinct terms
+    uint32_t seen_q = 0xFFFFFFFFu;
     for (uint32_t q = 0; q < n_queries; ++q) {
         if (q_offsets[q + 1] < q_offsets[q]) return fail(ix, SEBM25_E_INVALID, "search: q_offsets must be non-decreasing");
         for (uint64_t j = q_offsets[q] + AHEAD, e = std::min(q_offsets[q + 1] + AHEAD, n_q_terms); j < e; ++j) {
@@ -1522,14 +1526,23 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
             const uint32_t t = q_terms[j];
             if (t >= ix->V || list_len(t) == 0) continue;  // matches no row
             bool dup = false;
-            for (size_t x = start; x < nf; ++x) dup |= st.flat[x] == t;
+            if (nf - start < 64) {
+                for (size_t x = start; x < nf; ++x) dup |= st.flat[x] == t;
+            } else {  // a long query: the terms seen so far in a set
+                if (seen_q != q) {
+                    seen.clear();
+                    seen.insert(st.flat + start, st.flat + nf);
+                    seen_q = q;
+                }
+                dup = !seen.insert(t).second;
+            }
             if (dup) continue;  // `= ANY($1)`: a repeated term selects its rows once
             if (nf >= st.flat_cap) return fail(ix, SEBM25_E_RANGE, "search: too many query terms for the plan storage");
             st.flat[nf++] = t;
             len += list_len(t);
         }
-        if (nf - start > MAX_QUERY_TERMS)
-            return fail(ix, SEBM25_E_RANGE, "search: more than 255 distinct matching terms in one query");
+        if (nf - start > max_query_terms)
+            return fail(ix, SEBM25_E_RANGE, "search: more than " + std::to_string(max_query_terms) + " distinct matching terms in one query");
         // Stepwise kernels read the lists shortest first and treat the longest one specially; the sum of a
         // score still runs in the order the caller gave.  order = 3 bits per given position: where that term
         // now sits (identity for the general kernel, which keeps the given order).
@@ -1550,7 +1563,8 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
             for (size_t j = 0; j < nt; ++j) order |= phys_of[j] << (3 * j);
         }
         st.q_toff[q] = (uint32_t)start;
-        st.q_nt[q] = (uint32_t)nt | (order << 8);
+        st.q_nt[q] = (uint32_t)nt;
+        st.q_order[q] = order;
         st.q_len[q] = len;
         total_len += len;
     }
@@ -1586,6 +1600,7 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
     const uint32_t fast_t = ix->big_weights ? 0u : score_fast_max_terms();
     const uint32_t n_groups = score_fast_max_terms() + 1;
     uint32_t n = 0, n_tmp = 0;
+    info.n_wide_words = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
         const uint32_t ns = st.q_ns[q];
         if (!tmp_base) {
@@ -1596,8 +1611,12 @@ int plan_pass2(sebm25_index* ix, bool news, uint32_t n_queries, PlanStore& st, P
             QItem it{};
             it.q = q;
             it.term_off = st.q_toff[q];
-            it.n_terms = st.q_nt[q] & 0xFFu;
-            it.order = st.q_nt[q] >> 8;
+            it.n_terms = st.q_nt[q];
+            it.order = st.q_order[q];
+            if (it.n_terms > SCORE_REG_LISTS) {  // cursor and end of every list, in device memory
+                it.order = (uint32_t)info.n_wide_words;
+                info.n_wide_words += 2ull * it.n_terms;
+            }
             it.unit_lo = (uint32_t)((uint64_t)n_units * sl / ns);
             it.unit_hi = sl + 1 == ns ? 0xFFFFFFFFu : (uint32_t)((uint64_t)n_units * (sl + 1) / ns);
             it.direct = !tmp_base && ns == 1;
@@ -1637,6 +1656,7 @@ struct SearchBufs {  // device memory of one search call
     uint32_t *terms, *first, *nlists;
     uint32_t *t_unit, *t_mat, *t_tie, *t_count;
     double* t_score;
+    uint32_t* wide = nullptr;   // cursors of the items with more than SCORE_REG_LISTS lists (info.n_wide_words words)
 };
 
 // kernel arguments of one segment's scoring launch: statistics, url ranks and unit bases are the handle's (ix), lists and
@@ -1656,6 +1676,7 @@ ScoreArgs score_args_of(const sebm25_index* ix, const sebm25_index* seg, bool ne
     a.news = news ? 1 : 0;
     a.items = b.items;
     a.q_terms = b.terms;
+    a.wide_cur = b.wide;
     a.n_items = info.n_items;
     a.k = k;
     a.out_unit = d_unit; a.out_score = d_score; a.out_matched = d_mat; a.out_tie = d_tie; a.out_count = d_count;
@@ -1716,11 +1737,11 @@ int run_search(sebm25_index* ix, bool news, uint32_t n_queries, uint32_t k, cons
 void plan_store_of(sebm25_index* seg, const uint64_t* q_offsets, uint32_t n_queries, PlanStore& st) {
     SearchPlanVecs& v = seg->plan_vecs;
     v.flat.resize(std::max<size_t>(q_offsets[n_queries], 1));
-    for (std::vector<uint32_t>* x : {&v.q_toff, &v.q_nt, &v.q_ns, &v.first, &v.nlists}) x->resize(n_queries);
+    for (std::vector<uint32_t>* x : {&v.q_toff, &v.q_nt, &v.q_order, &v.q_ns, &v.first, &v.nlists}) x->resize(n_queries);
     v.q_len.resize(n_queries);
     v.bucket.resize(plan_buckets() + 1);
     st.flat = v.flat.data(); st.flat_cap = v.flat.size();
-    st.q_toff = v.q_toff.data(); st.q_nt = v.q_nt.data(); st.q_ns = v.q_ns.data(); st.q_len = v.q_len.data();
+    st.q_toff = v.q_toff.data(); st.q_nt = v.q_nt.data(); st.q_order = v.q_order.data(); st.q_ns = v.q_ns.data(); st.q_len = v.q_len.data();
     st.first = v.first.data(); st.nlists = v.nlists.data(); st.bucket = v.bucket.data();
 }
 void plan_items_of(sebm25_index* seg, uint32_t n_items, PlanStore& st) {
@@ -1766,9 +1787,10 @@ int search_segments(sebm25_index* ix, bool news, const uint32_t* q_terms, const 
         }
         HIP_TRY(ix, seg->q_items.ensure((size_t)std::max(info[s].n_items, 1u) * sizeof(QItem)));
         HIP_TRY(ix, seg->q_terms.ensure(std::max<size_t>(info[s].n_flat, 1) * 4));
+        HIP_TRY(ix, seg->q_wide.ensure(std::max<size_t>(info[s].n_wide_words, 1) * 4));
         SearchBufs b{seg->q_items.as<QItem>(), seg->q_terms.as<uint32_t>(), nullptr, nullptr,
                      ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
-                     ix->t_score.as<double>()};
+                     ix->t_score.as<double>(), seg->q_wide.as<uint32_t>()};
         return score_segment(ix, seg, news, k, st[s], info[s], b, d_unit, d_score, d_mat, d_tie, d_count);
     };
     if ((rc = plan_first_pass(0, ~0ull))) return rc;
@@ -1905,9 +1927,10 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
             d_tie = ix->o_tie.as<uint32_t>();
         }
     }
+    HIP_TRY(ix, ix->q_wide.ensure(std::max<size_t>(info.n_wide_words, 1) * 4));
     SearchBufs b{ix->q_items.as<QItem>(), ix->q_terms.as<uint32_t>(), ix->q_first.as<uint32_t>(), ix->q_n.as<uint32_t>(),
                  ix->t_unit.as<uint32_t>(), ix->t_mat.as<uint32_t>(), ix->t_tie.as<uint32_t>(), ix->t_count.as<uint32_t>(),
-                 ix->t_score.as<double>()};
+                 ix->t_score.as<double>(), ix->q_wide.as<uint32_t>()};
     if (segmented)
         rc = search_segments(ix, news, q_terms, q_offsets, n_queries, k, d_unit, d_score, d_mat, d_tie, d_count);
     else
@@ -1962,12 +1985,13 @@ int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms,
     NaHost& h = *ix->na_host;
     PlanStore st{};
     st.flat = h.flat; st.flat_cap = NA_MAX_TERMS;
-    st.q_toff = h.q_toff; st.q_nt = h.q_nt; st.q_ns = h.q_ns; st.q_len = h.q_len;
+    st.q_toff = h.q_toff; st.q_nt = h.q_nt; st.q_order = h.q_order; st.q_ns = h.q_ns; st.q_len = h.q_len;
     st.first = h.first; st.nlists = h.nlists; st.bucket = h.bucket;
     st.items = h.items; st.unsorted = h.unsorted; st.item_len = h.item_len; st.item_cap = NA_MAX_ITEMS;
     PlanInfo info;
     std::lock_guard<std::mutex> dev_lk(g_na_device_mu[ix->device]);
-    if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, NA_TMP_ENTRIES))) return rc;
+    // no storage for the cursors of wider queries here: at most SCORE_REG_LISTS distinct matching terms per query
+    if ((rc = plan_pass1(ix, news, q_terms, q_offsets, n_queries, k, st, info, NA_TMP_ENTRIES, SCORE_REG_LISTS))) return rc;
     if (info.n_items > NA_MAX_ITEMS) {  // too many unit ranges for the fixed item array: plan without splitting
         for (uint32_t q = 0; q < n_queries; ++q) h.q_ns[q] = 1;
         info.n_items = n_queries;

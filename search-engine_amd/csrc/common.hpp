@@ -191,8 +191,10 @@ struct QItem {
     uint32_t unit_lo, unit_hi;
     uint32_t out_slot;  // result list index (direct output row or temporary slice list)
     uint32_t direct;    // 1: writes the final result row
-    uint32_t order;     // stepwise kernels: 3 bits per term position as the caller gave it = its place in the list
+    uint32_t order;     // stepwise kernels: 3 bits per term position as the caller gave it = its place in the list;
+                        // items of more than SCORE_REG_LISTS lists: offset (words) of the item's cursors in wide_cur
 };
+constexpr uint32_t SCORE_REG_LISTS = 256;  // lists whose cursors the general kernel keeps in registers
 struct ScoreArgs {
     const uint32_t* row_ptr;
     const uint32_t* news_ptr;
@@ -204,6 +206,7 @@ struct ScoreArgs {
     int news;  // 0 web, 1 news
     const QItem* items;
     const uint32_t* q_terms;  // flattened, deduped, valid
+    uint32_t* wide_cur;       // cursor and end of every list of the items with more than SCORE_REG_LISTS lists
     uint32_t n_items;
     uint32_t k;
     // outputs: final rows [n_queries][k] and temporary slice lists [n_slices][k]

@@ -69,14 +69,16 @@ constexpr uint32_t topk_sorted_size(uint32_t cap) {
     while (s * 2 + 32 <= cap) s *= 2;
     return s;
 }
-template <int CAP, bool HAS_TIE = true, bool LAZY_ONLY = false>
+// MAT: the type the count of matching terms is held in (8 bits for the kernels of up to eight lists; the general
+// kernel and the merge of finished lists, where a query may hold any number of terms, keep 32).
+template <int CAP, bool HAS_TIE = true, bool LAZY_ONLY = false, typename MAT = unsigned char>
 struct TopK {
     static constexpr uint32_t S = topk_sorted_size(CAP), W = CAP - S;
     static_assert(W >= 32 && W <= 64 && (!LAZY_ONLY || HAS_TIE), "32 to 64 waiting slots");
     uint64_t* key;
     uint32_t* unit;
     uint32_t* tie_;          // only when HAS_TIE
-    unsigned char* mat;      // matched terms (at most 64)
+    MAT* mat;                // matched terms
     uint32_t ns, np;         // live entries of the sorted part, entries waiting behind it
     uint64_t thr_key;  // a candidate must rank before (thr_key, thr_tie) to matter
     uint32_t thr_tie;
@@ -98,7 +100,7 @@ struct TopK {
         key = reinterpret_cast<uint64_t*>(lds);
         unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
         tie_ = unit + CAP;
-        mat = reinterpret_cast<unsigned char*>(unit + CAP + TIES);
+        mat = reinterpret_cast<MAT*>(unit + CAP + TIES);
         ns = np = 0;
         thr_key = 0;
         thr_tie = 0xFFFFFFFFu;
@@ -112,7 +114,7 @@ struct TopK {
         __builtin_amdgcn_wave_barrier();
     }
     static constexpr uint32_t TIES = (HAS_TIE && !LAZY_ONLY) ? (uint32_t)CAP : 0u;  // tie-break keys held
-    static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + 1) + (size_t)TIES * 4 + 15) / 16 * 16; }
+    static constexpr size_t bytes() { return ((size_t)CAP * (8 + 4 + sizeof(MAT)) + (size_t)TIES * 4 + 15) / 16 * 16; }
 #ifdef SEBM25_MIDF_LDS  // experiment builds only
     static constexpr bool FILTER_MIDDLE_LISTS = true;
 #else
@@ -144,7 +146,7 @@ struct TopK {
             }
             unit[lo] = uh;
             unit[hi] = ul;
-            const unsigned char ml = mat[lo], mh = mat[hi];
+            const MAT ml = mat[lo], mh = mat[hi];
             mat[lo] = mh;
             mat[hi] = ml;
         }
@@ -201,7 +203,7 @@ struct TopK {
                     key[i] = rk;
                     unit[i] = ru;
                     if (HAS_TIE && !LAZY_ONLY) tie_[i] = rt;
-                    mat[i] = (unsigned char)rm;
+                    mat[i] = (MAT)rm;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -231,7 +233,7 @@ struct TopK {
             key[pos] = ck;
             if (HAS_TIE && !LAZY_ONLY && !lazy) tie_[pos] = ct;
             unit[pos] = cu;
-            mat[pos] = (unsigned char)cm;
+            mat[pos] = (MAT)cm;
         }
         np += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
@@ -283,19 +285,125 @@ __device__ __forceinline__ uint32_t lower_bound_unit(const uint32_t* post_unit, 
     return b;
 }
 
-// The general form: any number of lists up to 64 * SCORE_LIST_BLOCKS.  Lane l keeps the cursors of lists
-// l, l + 64, l + 128, ...
+// The general form.  Up to 64 * SCORE_LIST_BLOCKS lists: lane l keeps the cursors of lists l, l + 64, l + 128, ...
+// in registers; more lists: the cursors live in global memory (see the branch at the top).
 constexpr int SCORE_LIST_BLOCKS = 4;
 template <int CAP>
 __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
     __shared__ __align__(16) double acc[WIN];
-    __shared__ unsigned char cnt[WIN];
+    __shared__ uint32_t cnt[WIN];
     __shared__ uint32_t touched[WIN / 32];
-    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP, true, false, uint32_t>::bytes()];
 
     const QItem it = a.items[blockIdx.x];
     const uint32_t lane = lane_id();
     const uint32_t T = it.n_terms;
+    // one window's postings of one list into the accumulators; -> the list's cursor behind them
+    auto take_list = [&](uint32_t c, uint32_t e, double idf, uint32_t base, uint64_t wend) {
+        while (true) {
+            const uint32_t i = c + lane;
+            const bool valid = i < e;
+            const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
+            const bool in = valid && (uint64_t)u < wend;
+            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+            const uint32_t w = in ? a.post_w[i] : POST_HOLE;
+            if (w != POST_HOLE) {  // a hole only moves the cursor
+                const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
+                const uint32_t idx = u - base;
+                const uint32_t bit = 1u << (idx & 31u);
+                const uint32_t old = atomicOr(&touched[idx >> 5], bit);
+                if (old & bit) {
+                    acc[idx] = __dadd_rn(acc[idx], v);
+                    cnt[idx] = cnt[idx] + 1u;
+                } else {
+                    acc[idx] = v;
+                    cnt[idx] = 1;
+                }
+            }
+            c += n_in;
+            if (n_in < 64) break;
+        }
+        return c;
+    };
+    // the window's sums into the candidates: lane l owns units [base + 32 l, base + 32 l + 32)
+    auto harvest = [&](TopK<CAP, true, false, uint32_t>& tk, uint32_t base) {
+        uint32_t word = touched[lane];
+        touched[lane] = 0;
+        while (__ballot(word != 0)) {
+            const bool has = word != 0;
+            const uint32_t b = has ? (uint32_t)__ffs((int)word) - 1u : 0u;
+            word &= word - 1u;
+            const uint32_t idx = lane * 32u + b;
+            double s = 0.0;
+            uint32_t m = 0, unit = 0, tie = 0;
+            if (has) {
+                s = acc[idx];
+                m = cnt[idx];
+                unit = base + idx;
+                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+            }
+            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
+        }
+    };
+    auto write_result = [&](TopK<CAP, true, false, uint32_t>& tk) {
+        const size_t o = (size_t)it.out_slot * a.k;
+        if (it.direct)
+            tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                         a.out_count + it.out_slot);
+        else
+            tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+    };
+
+    if (T > 64u * SCORE_LIST_BLOCKS) {
+        // More lists than the lanes keep cursors for (`t.term = ANY($1)` takes any number of terms,
+        // search_service.py:33): cursor and end of every list live in global memory, two words per list at
+        // a.wide_cur + it.order, and are walked 64 lists at a time.  Same windows, same order of the sums.
+        uint32_t* wc = a.wide_cur + it.order;
+        for (uint32_t t = lane; t < T; t += 64u) {
+            const uint32_t term = a.q_terms[it.term_off + t];
+            const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+            const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+            const uint32_t c = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+            wc[2u * t] = c;
+            wc[2u * t + 1u] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, c, e, it.unit_hi);
+        }
+        touched[lane] = 0;
+        TopK<CAP, true, false, uint32_t> tk;
+        tk.init(topk_mem);
+        __builtin_amdgcn_wave_barrier();
+        while (true) {
+            uint32_t nxt = 0xFFFFFFFFu;
+            for (uint32_t t = lane; t < T; t += 64u) {
+                const uint32_t c = wc[2u * t], e = wc[2u * t + 1u];
+                if (c < e) nxt = min(nxt, a.post_unit[c]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor(nxt, off));
+            if (nxt == 0xFFFFFFFFu) break;
+            const uint32_t base = nxt & ~31u;
+            const uint64_t wend = (uint64_t)base + WIN;
+            for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+                const uint32_t t = t0 + lane;
+                uint32_t cur = 0, end = 0;
+                double idf_l = 0.0;
+                if (t < T) {
+                    cur = wc[2u * t];
+                    end = wc[2u * t + 1u];
+                    idf_l = __ddiv_rn(a.idf_used[a.q_terms[it.term_off + t]], 10.0);
+                }
+                const uint32_t nl = min(64u, T - t0);
+                for (uint32_t l = 0; l < nl; ++l) {  // lists in query-term order
+                    const uint32_t c = take_list(__shfl(cur, (int)l), __shfl(end, (int)l), __shfl(idf_l, (int)l), base, wend);
+                    if (lane == l) cur = c;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (t < T) wc[2u * t] = cur;
+            }
+            harvest(tk, base);
+        }
+        write_result(tk);
+        return;
+    }
 
     uint32_t my_cur[SCORE_LIST_BLOCKS], my_end[SCORE_LIST_BLOCKS];
     double my_idf[SCORE_LIST_BLOCKS];
@@ -314,7 +422,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         }
     }
     touched[lane] = 0;
-    TopK<CAP> tk;
+    TopK<CAP, true, false, uint32_t> tk;
     tk.init(topk_mem);
     __builtin_amdgcn_wave_barrier();
 
@@ -335,63 +443,15 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
             if ((uint32_t)blk * 64u >= T) break;
             const uint32_t nl = min(64u, T - (uint32_t)blk * 64u);
             for (uint32_t l = 0; l < nl; ++l) {  // lists in query-term order
-                uint32_t c = __shfl(my_cur[blk], (int)l);
-                const uint32_t e = __shfl(my_end[blk], (int)l);
-                const double idf = __shfl(my_idf[blk], (int)l);
-                while (true) {
-                    const uint32_t i = c + lane;
-                    const bool valid = i < e;
-                    const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
-                    const bool in = valid && (uint64_t)u < wend;
-                    const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-                    const uint32_t w = in ? a.post_w[i] : POST_HOLE;
-                    if (w != POST_HOLE) {  // a hole only moves the cursor
-                        const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
-                        const uint32_t idx = u - base;
-                        const uint32_t bit = 1u << (idx & 31u);
-                        const uint32_t old = atomicOr(&touched[idx >> 5], bit);
-                        if (old & bit) {
-                            acc[idx] = __dadd_rn(acc[idx], v);
-                            cnt[idx] = (unsigned char)(cnt[idx] + 1);
-                        } else {
-                            acc[idx] = v;
-                            cnt[idx] = 1;
-                        }
-                    }
-                    c += n_in;
-                    if (n_in < 64) break;
-                }
+                const uint32_t c = take_list(__shfl(my_cur[blk], (int)l), __shfl(my_end[blk], (int)l), __shfl(my_idf[blk], (int)l), base, wend);
                 if (lane == l) my_cur[blk] = c;
                 __builtin_amdgcn_wave_barrier();
             }
         }
 
-        // harvest the window: lane l owns units [base + 32 l, base + 32 l + 32)
-        uint32_t word = touched[lane];
-        touched[lane] = 0;
-        while (__ballot(word != 0)) {
-            const bool has = word != 0;
-            const uint32_t b = has ? (uint32_t)__ffs((int)word) - 1u : 0u;
-            word &= word - 1u;
-            const uint32_t idx = lane * 32u + b;
-            double s = 0.0;
-            uint32_t m = 0, unit = 0, tie = 0;
-            if (has) {
-                s = acc[idx];
-                m = cnt[idx];
-                unit = base + idx;
-                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
-            }
-            tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
-        }
+        harvest(tk, base);
     }
-
-    const size_t o = (size_t)it.out_slot * a.k;
-    if (it.direct)
-        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
-                     a.out_count + it.out_slot);
-    else
-        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+    write_result(tk);
 }
 
 // queries with at most FAST_T lists take the stepwise kernels below
@@ -945,11 +1005,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 // one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
 template <int CAP>
 __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
-    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP>::bytes()];
+    __shared__ __align__(16) unsigned char topk_mem[TopK<CAP, true, false, uint32_t>::bytes()];
     const uint32_t q = blockIdx.x;
     const uint32_t nl = a.n[q];
     if (nl == 0) return;
-    TopK<CAP> tk;
+    TopK<CAP, true, false, uint32_t> tk;
     tk.init(topk_mem);
     const uint32_t lane = lane_id();
     for (uint32_t l = 0; l < nl; ++l) {

@@ -23,7 +23,12 @@ import threading
 
 import numpy as np
 
-from .native import MAX_QUERY_TERMS, SRC_NEWS, SRC_WEB
+from .native import SRC_NEWS, SRC_WEB
+
+# A cap a deployment may put on the distinct indexed terms of one request (None: none).  The reference's
+# `t.term = ANY($1)` (search_service.py:33) has no limit and neither has the library; a request beyond a cap that
+# was set fails alone, not the batch it was coalesced into.
+MAX_QUERY_TERMS = None
 from .store import TEXT_DECODE_ERRORS, SqlStore, TokenExport, UrlRanker, _factorize, url_ranks
 
 
@@ -286,12 +291,13 @@ class SearchEngine:
             ex, ix = self.export, self.index
             queries = [list(dict.fromkeys(ex.term_index[t] for t in terms if t in ex.term_index)) for terms, _ in requests]
             kmax = max([int(limit) for _, limit in requests] + [1])
-            # unknown terms match nothing; a query beyond the library's limit fails alone, not the batch it came in
-            live = [i for i, q in enumerate(queries) if q and len(q) <= MAX_QUERY_TERMS]
+            # unknown terms match nothing; a query beyond the deployment's cap fails alone, not the batch it came in
+            cap = MAX_QUERY_TERMS if MAX_QUERY_TERMS is not None else float("inf")
+            live = [i for i, q in enumerate(queries) if q and len(q) <= cap]
             out = ix.search([queries[i] for i in live], kmax, source=source) if live else None
         res = [(np.zeros(0, np.uint32), np.zeros(0), np.zeros(0, np.uint32))] * len(requests)
         for i, q in enumerate(queries):
-            if len(q) > MAX_QUERY_TERMS:
+            if len(q) > cap:
                 res[i] = ValueError(f"query with {len(q)} distinct indexed terms: at most {MAX_QUERY_TERMS} are scored")
         for j, i in enumerate(live):
             # a result list cut at a smaller limit is a prefix of the list cut at a larger one

@@ -20,7 +20,6 @@ FIELD_TITLE, FIELD_DESCRIPTION, FIELD_BODY = 1, 2, 4
 ROWS_UNIT_MAJOR = 1
 DOC_DONE, DOC_WC_NULL = 1, 2
 PAD_UNIT = 0xFFFFFFFF
-MAX_QUERY_TERMS = 255     # distinct matching terms one query may hold (sebm25_search returns SEBM25_E_RANGE beyond)
 
 _ERR_NAMES = {1: "INVALID", 2: "RANGE", 3: "HIP", 4: "NOMEM", 5: "STATE", 6: "ORDER", 7: "INTERNAL"}
 

@@ -65,11 +65,31 @@ def test_query_edge_cases(built):
         np.testing.assert_array_equal(out["matched"][qi, :n], rm)
     assert out["matched"][2, 0] == 1  # a repeated term counts once
     with pytest.raises(se.Sebm25Error):
-        ix.search([list(range(0, 300))], 10)  # more than 255 distinct matching terms
-    with pytest.raises(se.Sebm25Error):
         ix.search([[1]], 0)
     with pytest.raises(se.Sebm25Error):
         ix.search([[1]], 5000)
+
+
+@pytest.mark.parametrize("n_q_terms", [256, 257, 300, 600, 1500, 6000])
+def test_queries_with_hundreds_of_terms(built, n_q_terms):
+    """`t.term = ANY($1)` takes any number of terms (search_service.py:33): a pasted paragraph is a query.  Beyond 256
+    lists the scoring kernel keeps its cursors in global memory; results stay bit for bit those of the oracle."""
+    c, orc, ix = built
+    rng = np.random.default_rng(n_q_terms)
+    qs = [rng.choice(c["n_terms"], size=n_q_terms, replace=False).astype(np.uint32) for _ in range(3)]
+    qs.append(np.arange(n_q_terms, dtype=np.uint32))          # the most frequent terms: long lists
+    rank = rng.permutation(c["n_docs"]).astype(np.uint32)
+    for source, k, with_rank in ((se.SRC_WEB, 10, False), (se.SRC_WEB, 210, True), (se.SRC_NEWS, 10, False), (se.SRC_WEB, 2000, False)):
+        ix.set_url_rank(se.SRC_WEB, rank if with_rank else None)
+        out = ix.search(qs, k, source=source)
+        for qi, q in enumerate(qs):
+            ru, rs, rm = orc.search(q, k, source=source, url_rank=rank if with_rank and source == se.SRC_WEB else None, level="csr")
+            n = int(out["count"][qi])
+            assert n == len(ru)
+            np.testing.assert_array_equal(out["unit"][qi, :n], ru)
+            np.testing.assert_array_equal(out["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
+            np.testing.assert_array_equal(out["matched"][qi, :n], rm)
+    ix.set_url_rank(se.SRC_WEB, None)
 
 
 def test_missing_idf_is_one_and_url_rank_breaks_ties(built):
