@@ -71,6 +71,7 @@ struct sebm25_index {
     bool keep_rows = false;   // this segment's sorted rows are wanted right away (update segments)
     bool fused = true;        // SEBM25_FUSED_POSTINGS=0: always the separate posting pass
     bool built_fused = false; // the slots this segment holds were written by the last sort pass
+    uint64_t max_rows = MAX_ROWS;  // rows one shard holds (SEBM25_TEST_MAX_ROWS lowers it: tests of what a rank past it does)
     const uint32_t* wc_dev = nullptr;       // device views of the last build's word_count / doc_flags arrays
     const uint8_t* flags_dev = nullptr;
 
@@ -641,7 +642,7 @@ int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
 int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
     if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
-    if (in->n_rows > MAX_ROWS) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
+    if (in->n_rows > ix->max_rows) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
     if (in->n_rows && (!in->term_id || !in->unit_id || !in->tf || !in->meta))
         return fail(ix, SEBM25_E_INVALID, "build: a row array is NULL");
     if (in->flags & ~SEBM25_ROWS_UNIT_MAJOR) return fail(ix, SEBM25_E_INVALID, "build: unknown flag");
@@ -1127,6 +1128,7 @@ int sebm25_create(int device, sebm25_index** out) {
     ix->device = device;
     if (const char* e = getenv("SEBM25_SORT_BITS")) ix->sort_bits = std::min(std::max(atoi(e), 4), (int)SORT_MAX_BITS);
     if (const char* e = getenv("SEBM25_FUSED_POSTINGS")) ix->fused = atoi(e) != 0;  // 0: always the separate posting pass
+    if (const char* e = getenv("SEBM25_TEST_MAX_ROWS")) ix->max_rows = std::min<uint64_t>(MAX_ROWS, strtoull(e, nullptr, 10));
     {
         // set-up of sebm25_search_noalloc: this GPU's address of the fixed device array and the pinned host plan storage
         DeviceGuard g(device);

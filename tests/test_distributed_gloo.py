@@ -53,18 +53,21 @@ class OracleEngine:
     def search(self, queries, k, source, out):
         base = self.base[0] if source == 1 else self.base[1]
         for key in ("unit", "tie"):
-            out[key].fill_(-1)
+            if key in out:
+                out[key].fill_(-1)
         out["score"].zero_(); out["matched"].zero_()
         for i, q in enumerate(queries):
             u, s, m = self.orc.search(np.asarray(q, np.uint32), k, source=source, unit_base=base, level="csr")
             n = len(u)
             out["count"][i] = n
             out["unit"][i, :n] = torch.from_numpy(u.astype(np.int32))
-            out["tie"][i, :n] = torch.from_numpy(u.astype(np.int32))     # default tie-break key: global unit id
+            if "tie" in out:
+                out["tie"][i, :n] = torch.from_numpy(u.astype(np.int32))     # default tie-break key: global unit id
             out["score"][i, :n] = torch.from_numpy(s)
             out["matched"][i, :n] = torch.from_numpy(m.astype(np.int32))
 
     def merge_topk(self, n_lists, nq, k, unit, score, matched, tie, count, out):
+        out["unit"].fill_(-1); out["score"].zero_(); out["matched"].zero_(); out["tie"].fill_(-1)   # padding as the library writes it
         for q in range(nq):
             c = []
             for l in range(n_lists):
@@ -95,6 +98,17 @@ def _worker(rank, world, port, n_docs, n_art, V, result_path, update=False):
     qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 20, 3)
     web = sh.search(qs, 12, source=1)
     news = sh.search(qs, 12, source=2)
+    # the query-partitioned merge (what large batches take) gives the same rows as the all-gather merge; 19 queries: a
+    # count the ranks do not divide
+    small_bytes = sh.last_exchange_bytes
+    sh.partition_min_entries = 1
+    for src, ref in ((1, web), (2, news)):
+        for n in (20, 19):
+            part = sh.search(qs[:n], 12, source=src)
+            for key in ("unit", "score", "matched", "count"):
+                np.testing.assert_array_equal(part[key], ref[key][:n])
+    assert sh.last_exchange_bytes > 0 and small_bytes > 0
+    sh.partition_min_entries = 16384
     if update:
         # the first five docs of every shard are crawled again (rows of a corpus with another seed)
         c2 = O.gen_corpus(O.make_spec(seed=99, n_terms=V, n_docs=d1 - d0, n_articles=0, doc_begin=d0, body_min=30, body_max=90))
@@ -183,3 +197,91 @@ def test_shard_ranges_cover_everything():
             r = [shard_range(n, g, world) for g in range(world)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[g][1] == r[g + 1][0] for g in range(world - 1))
+
+
+def _worker_growth_and_failure(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from search_engine_amd.native import Sebm25Error
+    from search_engine_amd.sharded import ShardedIndex, ShardError
+
+    V, per = 1500, 100
+    c = O.gen_corpus(O.make_spec(n_terms=V, n_docs=per, doc_begin=rank * per, body_min=20, body_max=60))
+    sh = ShardedIndex(OracleEngine(), "cpu")
+    out = {}
+    # (1) bases with headroom: rank r owns global ids [200 r, 200 r + 100)
+    sh.build(c["term_id"], c["unit_id"], c["tf"], c["meta"], V, per, 0, c["word_count"], doc_base=200 * rank)
+    # (2) rank 0 gains 150 docs: its range would reach into rank 1's -> ValueError on every rank, nothing changed
+    grow = 150 if rank == 0 else 0
+    z32, z8 = np.zeros(0, np.uint32), np.zeros(0, np.uint8)
+    wc = np.concatenate([c["word_count"], np.zeros(grow, np.uint32)])
+    try:
+        sh.update(z32, z32, z32, z8, V, per + grow, 0, wc)
+        out["overlap"] = "no error"
+    except ValueError as e:
+        out["overlap"] = str(e)
+    assert sh.n_docs == per
+    # (3) rank 0 gains 50 docs (inside its headroom), with rows: fine, and the new docs are found under their global ids
+    grow = 50 if rank == 0 else 0
+    n2 = per + grow
+    c2 = O.gen_corpus(O.make_spec(seed=5, n_terms=V, n_docs=grow, body_min=20, body_max=60)) if grow else None
+    wc = np.concatenate([c["word_count"], c2["word_count"]]) if grow else c["word_count"]
+    if grow:
+        sh.update(c2["term_id"], c2["unit_id"] + np.uint32(per), c2["tf"], c2["meta"], V, n2, 0, wc,
+                  changed_docs=np.arange(per, n2, dtype=np.uint32), unit_major=True)
+    else:
+        sh.update(z32, z32, z32, z8, V, n2, 0, wc)
+    qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 15, 3)
+    res = sh.search(qs, 10, source=1)
+    out.update({f"grown_{k}": v for k, v in res.items()})
+    # (4) the local step fails on rank 1 only: both ranks get ShardError, nobody waits in the all-reduce
+    class Failing(OracleEngine):
+        def build_local(self, *a, **kw):
+            raise Sebm25Error(2, "build: more than 2^32 - 4096 rows in one shard")
+    sh2 = ShardedIndex(Failing() if rank == 1 else OracleEngine(), "cpu")
+    try:
+        sh2.build(c["term_id"], c["unit_id"], c["tf"], c["meta"], V, per, 0, c["word_count"], doc_base=200 * rank)
+        out["failure"] = "no error"
+    except ShardError as e:
+        out["failure"] = f"ShardError n_failed={e.n_failed} code={e.code}"
+    np.savez(result_path % rank, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_growth_needs_headroom_and_a_failing_rank_fails_all(tmp_path):
+    from oracle import oracle as O
+
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = str(tmp_path / "g%d.npz")
+    mp.start_processes(_worker_growth_and_failure, args=(world, port, path), nprocs=world, join=True, start_method="spawn")
+    r = [np.load(path % i) for i in range(world)]
+    for x in r:
+        assert "overlap" in str(x["overlap"]) and "document id ranges" in str(x["overlap"])
+    assert str(r[0]["failure"]) == "ShardError n_failed=1 code=None"      # rank 0's own step was fine
+    assert str(r[1]["failure"]) == "ShardError n_failed=1 code=2"
+    # the grown index equals an unsharded one over the same global ids: docs 0..149 (rank 0) and 200..299 (rank 1)
+    V, per = 1500, 100
+    a = O.gen_corpus(O.make_spec(n_terms=V, n_docs=per, doc_begin=0, body_min=20, body_max=60))
+    b = O.gen_corpus(O.make_spec(n_terms=V, n_docs=per, doc_begin=per, body_min=20, body_max=60))
+    g = O.gen_corpus(O.make_spec(seed=5, n_terms=V, n_docs=50, body_min=20, body_max=60))
+    rows = {k: np.concatenate([a[k], g[k] if k != "unit_id" else g[k] + np.uint32(per), b[k] if k != "unit_id" else b[k] + np.uint32(200)])
+            for k in ("term_id", "unit_id", "tf", "meta")}
+    wc = np.zeros(300, np.uint32)
+    wc[:100], wc[100:150], wc[200:300] = a["word_count"], g["word_count"], b["word_count"]
+    flags = np.zeros(300, np.uint8)
+    flags[:150] = 1
+    flags[200:] = 1
+    orc = O.OracleIndex(rows["term_id"], rows["unit_id"], rows["tf"], rows["meta"], V, 300, 0, wc, flags)
+    qs = O.gen_queries(3, V, O.zipf_cdf(V), 5, 15, 3)
+    for x in r:
+        for qi, q in enumerate(qs):
+            u, sc, m = orc.search(q, 10, source=1, level="csr")
+            n = int(x["grown_count"][qi])
+            assert n == len(u)
+            np.testing.assert_array_equal(x["grown_unit"][qi, :n], u)
+            np.testing.assert_array_equal(x["grown_score"][qi, :n], sc)
