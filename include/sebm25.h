@@ -247,9 +247,11 @@ int sebm25_search(sebm25_index* ix, int source, const uint32_t* q_terms, const u
                   uint32_t* out_matched, uint32_t* out_tie, uint32_t* out_count);
 
 /*
- * sebm25_search for callers that cannot allocate: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, results
- * and ordering as sebm25_search, but the call allocates nothing on the device or the host: the work
+ * sebm25_search for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc,
+ * code that runs beside a graph capture on another stream.  It has no counterpart in the reference.  (The
+ * call itself is not capturable: it plans on the host, copies the plan and waits for its stream.)  Same
+ * arguments, results and ordering as sebm25_search, but a successful call allocates nothing on the device or
+ * the host (a failing one builds its error text; with timing enabled the first call creates its events): the work
  * items, the deduplicated query terms and the temporary result lists of queries that are split by
  * unit range live in one fixed device array of about 2.8 MB per GPU (held from sebm25_create of the
  * first handle on that GPU until the process ends), and the host-side plan in pinned storage of the

@@ -2006,8 +2006,15 @@ int sebm25_search_noalloc(sebm25_index* ix, int source, const uint32_t* q_terms,
                  reinterpret_cast<uint32_t*>(base + NA_OFF_T_UNIT), reinterpret_cast<uint32_t*>(base + NA_OFF_T_MAT),
                  reinterpret_cast<uint32_t*>(base + NA_OFF_T_TIE), reinterpret_cast<uint32_t*>(base + NA_OFF_T_COUNT),
                  reinterpret_cast<double*>(base + NA_OFF_T_SCORE)};
-    if ((rc = run_search(ix, news, n_queries, k, st, info, b, out_unit, out_score, out_matched, out_tie, out_count))) return rc;
-    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    rc = run_search(ix, news, n_queries, k, st, info, b, out_unit, out_score, out_matched, out_tie, out_count);
+    // also after a failure: what was queued may still use this GPU's shared array and the pinned plan, which the next
+    // call (of any handle on this GPU) takes over when the device lock is released
+    const hipError_t e_sync = hipStreamSynchronize(ix->stream);
+    if (rc) {
+        (void)hipGetLastError();
+        return rc;
+    }
+    HIP_TRY(ix, e_sync);
     return SEBM25_OK;
     ABI_CATCH(ix)
 }

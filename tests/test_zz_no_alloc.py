@@ -22,6 +22,13 @@ def _dev_out(nq, k):
     return out
 
 
+def _noalloc_views(out, nq, k):
+    """Views into preallocated outputs, contiguous and large enough for nq x k results (no allocation)."""
+    v = {key: t.view(-1)[:nq * k].view(nq, k) for key, t in out.items() if key != "count"}
+    v["count"] = out["count"][:nq]
+    return v
+
+
 def _same(a, b):
     for key in ("unit", "matched", "tie", "count"):
         assert np.array_equal(a[key].cpu().numpy(), b[key].cpu().numpy()), key
@@ -46,6 +53,18 @@ def test_noalloc_matches_search_on_two_calls_in_a_row(gpu_index_factory):
                 ix.search(qs, k, source=source, out=ref)
                 ix.search_noalloc(qs, k, got, source=source)
                 _same(ref, got)
+    # no device memory is taken or given back by the calls: free memory is the same before and after a series of them
+    # (the outputs are allocated before the first reading)
+    import torch
+
+    got = _dev_out(len(big), 220)
+    ix.search_noalloc(big, 220, got)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for qs, k in ((big, 220), (small, 220), (big[:100], 10), (big, 220)):
+        ix.search_noalloc(qs, k, _noalloc_views(got, len(qs), k))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
     # without the optional tie output
     ref, got = _dev_out(len(small), 10), _dev_out(len(small), 10)
     del got["tie"]
