@@ -316,3 +316,48 @@ def test_sharded_update_equals_unsharded_rebuild(gpu_index_factory):
             np.testing.assert_array_equal(merged["unit"][qi, :n], ru)
             np.testing.assert_array_equal(merged["score"][qi, :n].view(np.uint64), rs.view(np.uint64))
             np.testing.assert_array_equal(merged["matched"][qi, :n], rm)
+
+
+def test_failed_update_leaves_the_index_as_it_was(gpu_index_factory):
+    """An update that cannot be applied — here: id spaces grown so far that the packed row has too few bits left for the
+    frequencies the update segment already holds (SEBM25_E_RANGE) — is refused before a row of the index changes:
+    statistics, postings and searches are those of before, the handle is still finalized, and the next valid update
+    works."""
+    rng = np.random.default_rng(7)
+    c = O.gen_corpus(O.make_spec(n_terms=2000, n_docs=300, n_articles=20))
+    tb = Table(c)
+    hot = np.arange(10, 40)
+    upd, ref = gpu_index_factory(), gpu_index_factory()
+    full_build(upd, tb)
+    cd, ca = apply_random_batch(rng, tb, hot)          # a first update: the index now holds an update segment
+    t, u, f, m = tb.arrays(cd, ca)
+    upd.update(t, u, f, m, tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=cd, changed_articles=ca)
+    full_build(ref, tb)
+    assert_same_index(upd, ref, tb, rng, hot)
+    before = upd.info()
+    # 2^21 terms and 2^21 docs leave 61 - 21 - 21 = 19 bits for tf; the update segment was packed with 41
+    big = 1 << 21
+    wc = np.zeros(big, np.uint32)
+    wc[:tb.n_docs] = tb.word_count
+    fl = np.zeros(big, np.uint8)
+    fl[:tb.n_docs] = tb.flags
+    rows = tb.arrays([0], [])
+    with pytest.raises(se.Sebm25Error) as e:
+        upd.update(*rows, big, big, tb.n_articles, wc, fl, changed_docs=[0])
+    assert e.value.code == 2
+    upd.n_terms, upd.n_docs, upd.n_articles = tb.n_terms, tb.n_docs, tb.n_articles     # the sizes the index still has
+    after = upd.info()
+    assert (after.n_segments, after.n_rows, after.n_postings, after.n_dead_rows, after.n_terms, after.n_docs) == \
+           (before.n_segments, before.n_rows, before.n_postings, before.n_dead_rows, before.n_terms, before.n_docs)
+    assert_same_index(upd, ref, tb, rng, hot)          # searches run: the handle is still finalized
+    # a row of a unit that is not listed: refused as well, same state
+    with pytest.raises(se.Sebm25Error) as e:
+        upd.update(*tb.arrays([1, 2], []), tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=[1])
+    assert e.value.code == 1
+    assert_same_index(upd, ref, tb, rng, hot)
+    # and the next valid update is applied on top of the unchanged state
+    cd, ca = apply_random_batch(rng, tb, hot)
+    t, u, f, m = tb.arrays(cd, ca)
+    upd.update(t, u, f, m, tb.n_terms, tb.n_docs, tb.n_articles, tb.word_count, tb.flags, changed_docs=cd, changed_articles=ca)
+    full_build(ref, tb)
+    assert_same_index(upd, ref, tb, rng, hot)
