@@ -644,6 +644,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     const uint32_t lane = lane_id();
     const uint64_t lt = lanemask_lt();
     constexpr uint32_t INF = 0xFFFFFFFFu;
+    auto ballot = [](bool c) { return (uint64_t)__builtin_amdgcn_ballot_w64(c); };
+    auto lanes = [](uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
 
     uint32_t my_cur = 0, my_end = 0;
     double my_idf = 0.0;
@@ -815,65 +817,71 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #pragma unroll
             for (int j = 0; j < BM; ++j) {
                 if (j >= nb(t)) break;
-                const bool in = u[t][j] <= Fc;
-                if (!__ballot(in)) continue;
-                bool s = in && w[t][j] != POST_HOLE;  // a hole only leaves its chunk
+                // Every yes/no per posting is a wave-wide lane mask in scalar registers: masks of plain compares cost
+                // nothing beyond the compare, combining them is scalar work, and only selects and guarded accesses turn
+                // one back into a per-lane condition.
+                const uint64_t in_m = ballot(u[t][j] <= Fc);
+                if (!in_m) continue;
+                uint64_t s_m = in_m & ballot(w[t][j] != POST_HOLE);  // a hole only leaves its chunk
 #ifdef SEBM25_EXP_NOINSERT
-                if (t < T - 1) s = false;
+                if (t < T - 1) s_m = 0;
 #endif
-                bool found = false;
+                uint64_t found_m = 0;
                 if (t == T - 1 || (MIDF && t >= 1)) {
                     // the filtered lists: add to units that are in the table
-                    if (probe && __ballot(s)) {
+                    if (probe && s_m) {
                         // nearly every lane is done after one look (its slot is empty or holds its unit)
+                        const bool s = lanes(s_m);
                         const uint32_t un = u[t][j];
                         uint32_t h = (un ^ (un >> 9)) & (STEP_SLOTS - 1u);
                         const uint32_t tg0 = s ? tag[h] : HASH_EMPTY;
-                        found = s && tg0 == un;
-                        bool more = s && tg0 != un && tg0 != HASH_EMPTY;
-                        if (__ballot(more)) {
-                            if (more) {
+                        found_m = s_m & ballot(tg0 == un);
+                        const uint64_t more_m = s_m & ~found_m & ballot(tg0 != HASH_EMPTY);
+                        if (more_m) {
+                            bool later = false;
+                            if (lanes(more_m)) {
                                 while (true) {
                                     h = (h + 1u) & (STEP_SLOTS - 1u);
                                     const uint32_t tg = tag[h];
                                     if (tg == un) {
-                                        found = true;
+                                        later = true;
                                         break;
                                     }
                                     if (tg == HASH_EMPTY) break;
                                 }
                             }
+                            found_m |= ballot(later);
                         }
-                        if (found) wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
+                        if (lanes(found_m)) wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (t < T - 1) s = s && !found && w[t][j] >= w_mid[t];  // what is left goes into the table below
+                    if (t < T - 1) s_m &= ~found_m & ballot(w[t][j] >= w_mid[t]);  // what is left goes into the table below
                 } else if (MIDF && FIRST_F == 0) {
-                    s = s && w[t][j] >= w_mid[t];  // the shortest list: nothing to look up, the same bound
+                    s_m &= ballot(w[t][j] >= w_mid[t]);  // the shortest list: nothing to look up, the same bound
                 }
                 if (t == T - 1) {
                     // a unit that only the longest list holds has its final score already: straight to the candidates
-                    const bool alone = s && !found && w[t][j] >= w_min;
-                    if (__ballot(alone)) {
+                    const uint64_t alone_m = s_m & ~found_m & ballot(w[t][j] >= w_min);
+                    if (alone_m) {
                         const double sc = __dmul_rn(idf_last, (double)w[t][j]);
-                        const bool may = alone && sc >= tk.thr_score;
-                        if (__ballot(may)) {
+                        const uint64_t may_m = alone_m & ballot(sc >= tk.thr_score);
+                        if (may_m) {
+                            const bool may = lanes(may_m);
                             uint32_t tie = 0;
                             if (may && !LAZY) tie = HAS_RANK ? a.url_rank[u[t][j]] : u[t][j] + a.unit_base;
                             tk.offer(may, score_key(sc), tie, u[t][j] + a.unit_base, 1u, a.k);
                         }
                     }
-                    s = false;  // the longest list never inserts
+                    s_m = 0;  // the longest list never inserts
                 }
-                const uint64_t sm = __ballot(s);
 #ifdef SEBM25_EXP_STATS
-                st_ins += (uint32_t)__popcll(sm);
-                st_passes += sm ? 1u : 0u;
+                st_ins += (uint32_t)__popcll(s_m);
+                st_passes += s_m ? 1u : 0u;
 #endif
-                if (sm) {
+                if (s_m) {
                     bool fresh = false;
                     uint32_t h = 0;
-                    if (s) {
+                    if (lanes(s_m)) {
                         const uint32_t un = u[t][j];
                         h = (un ^ (un >> 9)) & (STEP_SLOTS - 1u);
                         while (true) {
@@ -887,7 +895,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         }
                         wfield[h * WF + (uint32_t)t] = (unsigned short)(w[t][j] + 1u);
                     }
-                    const uint64_t fm = __ballot(fresh);
+                    const uint64_t fm = ballot(fresh);
                     if (fresh) used(n_used + (uint32_t)__popcll(fm & lt)) = (unsigned short)h;
                     n_used += (uint32_t)__popcll(fm);
 #ifndef SEBM25_EXP_NOPROBE
@@ -895,7 +903,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 #endif
                     __builtin_amdgcn_wave_barrier();
                 }
-                if (!advance) u[t][j] = in ? INF : u[t][j];  // used slots leave their chunk
+                if (!advance) u[t][j] = lanes(in_m) ? INF : u[t][j];  // used slots leave their chunk
             }
             if (advance) {  // the block in flight becomes the current one, the one behind it is requested
 #pragma unroll
@@ -955,12 +963,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 }
             }
             // most units cannot enter the top k any more: test the score alone before anything else
-            const bool may = has && s >= tk.thr_score;
+            const uint64_t may_m = ballot(s >= tk.thr_score) & (take >= 64u ? ~0ull : (1ull << take) - 1ull);
 #ifdef SEBM25_EXP_STATS
             ++st_rounds;
-            st_offers += (uint32_t)__popcll(__ballot(may));
+            st_offers += (uint32_t)__popcll(may_m);
 #endif
-            if (__ballot(may)) {
+            if (may_m) {
+                const bool may = lanes(may_m);
                 uint32_t tie = 0;
                 if (may && !LAZY) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
                 tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
