@@ -60,8 +60,7 @@ struct sebm25_index {
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
     DevBuf url_rank_web, url_rank_news;
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
-    uint32_t* post_unit = nullptr;
-    uint32_t* post_w = nullptr;  // weights in tenths
+    Slot* post = nullptr;  // one slot per sorted row: unit, weight in tenths (or POST_HOLE)
     const uint64_t* sorted_rows = nullptr;  // the sorted packed rows this segment was built from (read again by updates)
     // A build whose last sort pass wrote the posting slots has no sorted rows: the input of that pass (the
     // rows ordered by the earlier digits) is kept with the pass's offsets, and the rows are sorted out of it
@@ -416,13 +415,11 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
 int post_sorted(sebm25_index* ix, const uint64_t* sorted, uint64_t* slots) {
     const uint64_t R = ix->R;
     const uint32_t V = ix->V;
-    const size_t Rcap = std::max<uint64_t>(R, 1);
     uint64_t* scal = ix->scalars.as<uint64_t>();
     uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
     uint32_t* row_ptr = ix->row_ptr.as<uint32_t>();
     uint32_t* news_ptr = ix->news_ptr.as<uint32_t>();
-    ix->post_unit = reinterpret_cast<uint32_t*>(slots);
-    ix->post_w = reinterpret_cast<uint32_t*>(slots) + Rcap + POST_PAD;
+    ix->post = reinterpret_cast<Slot*>(slots);
     ix->built_fused = false;
     // one contiguous range of rows per wavefront
     uint64_t chunk2 = (R + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS;
@@ -433,7 +430,7 @@ int post_sorted(sebm25_index* ix, const uint64_t* sorted, uint64_t* slots) {
     HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
     HIP_TRY(ix, ix->scan_tmp.ensure(std::max(row_ptr_fill_tmp_words(V), postings_tmp_words(n_chunks)) * 4));
     phase_begin(ix, "postings");
-    launch_postings(sorted, R, chunk2, n_chunks, ix->fmt, V, ix->post_unit, ix->post_w, row_ptr, news_ptr,
+    launch_postings(sorted, R, chunk2, n_chunks, ix->fmt, V, ix->post, row_ptr, news_ptr,
                     ix->df_local.as<uint32_t>(), scal, ix->scan_tmp.as<uint32_t>(), err_dev, ix->stream);
     phase_end(ix);
     phase_begin(ix, "term_stats");
@@ -501,8 +498,7 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
         HIP_TRY(ix, hipMemsetAsync(news_ptr, 0, (size_t)V * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
         HIP_TRY(ix, hipMemsetAsync(ix->term_rows.p, 0, (size_t)V * 4, ix->stream));
-        ix->post_unit = ix->sortA.as<uint32_t>();
-        ix->post_w = ix->sortA.as<uint32_t>() + 1;
+        ix->post = ix->sortA.as<Slot>();
         ix->n_pass = 0;
         ix->built_fused = false;
         return SEBM25_OK;
@@ -559,14 +555,12 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
         phase_end(ix);
         if (fuse && p == 1) {
             // the posting slots take the place the sorted rows would have had
-            ix->post_unit = reinterpret_cast<uint32_t*>(dst);
-            ix->post_w = reinterpret_cast<uint32_t*>(dst) + Rcap + POST_PAD;
+            ix->post = reinterpret_cast<Slot*>(dst);
             HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
             HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
-            HIP_TRY(ix, hipMemsetAsync(ix->post_unit + R, 0, (size_t)POST_PAD * 4, ix->stream));   // what lies behind the last slot
-            HIP_TRY(ix, hipMemsetAsync(ix->post_w + R, 0xFF, (size_t)POST_PAD * 4, ix->stream));   // reads as holes
+            HIP_TRY(ix, hipMemsetAsync(ix->post + R, 0xFF, (size_t)POST_PAD * sizeof(Slot), ix->stream));   // what lies behind the last slot reads as holes
             phase_begin(ix, "scatter_postings");
-            launch_sort_scatter_post(src_packed, R, G, shift, bits, ctx, prefix, group_off, ix->post_unit, ix->post_w, news_ptr,
+            launch_sort_scatter_post(src_packed, R, G, shift, bits, ctx, prefix, group_off, ix->post, news_ptr,
                                      ix->df_local.as<uint32_t>(), ix->scan_tmp.as<uint32_t>(), scal, ix->stream);
             phase_end(ix);
             phase_begin(ix, "term_stats");
@@ -621,7 +615,7 @@ int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
     }
     if ((dev_err & DEV_NEED_FIXUP) && !(dev_err & (DEV_ERR_RANGE | DEV_ERR_ORDER))) {
         // rare runs the streaming kernel leaves to an exact second look
-        launch_postings_fixup(ix->sorted_rows, ix->R, ix->fmt, ix->post_w, err_dev, ix->stream);
+        launch_postings_fixup(ix->sorted_rows, ix->R, ix->fmt, ix->post, err_dev, ix->stream);
         HIP_TRY(ix, hipGetLastError());
         HIP_TRY(ix, hipMemcpyAsync(h + 7, scal + 7, 8, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -893,7 +887,7 @@ int do_update(sebm25_index* ix, const sebm25_rows* in, const uint32_t* chg_docs,
         for (size_t s = 0; s < segs.size(); ++s) {
             sebm25_index* g = segs[s];
             launch_tombstone(g->sorted_rows, g->R, g->fmt, ix->chg_web.as<uint32_t>(), ix->chg_news.as<uint32_t>(),
-                             ix->chg_coarse.as<uint32_t>(), cw, c_words, shift, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post_w, g->df_local.as<uint32_t>(),
+                             ix->chg_coarse.as<uint32_t>(), cw, c_words, shift, g->dead_web.as<uint32_t>(), g->dead_news.as<uint32_t>(), g->post, g->df_local.as<uint32_t>(),
                              g->term_rows.as<uint32_t>(), ix->upd_counts.as<unsigned long long>() + 4 * s, ix->stream);
             launch_bitmap_or(g->dead_web.as<uint32_t>(), ix->chg_web.as<uint32_t>(), (uint32_t)(((size_t)g->n_docs + 31) / 32), ix->stream);
             launch_bitmap_or(g->dead_news.as<uint32_t>(), ix->chg_news.as<uint32_t>(), (uint32_t)(((size_t)g->n_articles + 31) / 32), ix->stream);
@@ -1411,7 +1405,7 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
     // export compacts them on the host into the CSR the ABI describes, a term's postings from several segments
     // merged by unit.
     const std::vector<sebm25_index*> segs = all_segments(ix);
-    std::vector<std::vector<uint32_t>> su(segs.size()), sw(segs.size());
+    std::vector<std::vector<Slot>> sl(segs.size());
     uint64_t P_all = 0;
     for (size_t s = 0; s < segs.size(); ++s) {
         sebm25_index* seg = segs[s];
@@ -1421,12 +1415,8 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
             if (seg != ix) ix->err = seg->err;
             return rc;
         }
-        su[s].resize(seg->R);
-        sw[s].resize(seg->R);
-        if (seg->R) {
-            HIP_TRY(ix, hipMemcpyAsync(su[s].data(), seg->post_unit, (size_t)seg->R * 4, hipMemcpyDeviceToHost, ix->stream));
-            HIP_TRY(ix, hipMemcpyAsync(sw[s].data(), seg->post_w, (size_t)seg->R * 4, hipMemcpyDeviceToHost, ix->stream));
-        }
+        sl[s].resize(seg->R);
+        if (seg->R) HIP_TRY(ix, hipMemcpyAsync(sl[s].data(), seg->post, (size_t)seg->R * sizeof(Slot), hipMemcpyDeviceToHost, ix->stream));
         P_all += seg->P;
     }
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -1451,7 +1441,7 @@ int sebm25_get_postings(sebm25_index* ix, uint64_t* row_ptr, uint64_t* news_ptr,
                 const uint32_t e = news ? seg->h_row_ptr[t + 1] : seg->h_news_ptr[t];
                 const size_t before = run.size();
                 for (uint32_t i = b; i < e; ++i)
-                    if (sw[s][i] != POST_HOLE) run.emplace_back(su[s][i], sw[s][i]);
+                    if (sl[s][i].y != POST_HOLE) run.emplace_back(sl[s][i].x, sl[s][i].y);
                 if (run.size() > before) ++from;
             }
             if (from > 1) std::sort(run.begin(), run.end());
@@ -1669,8 +1659,7 @@ ScoreArgs score_args_of(const sebm25_index* ix, const sebm25_index* seg, bool ne
     ScoreArgs a{};
     a.row_ptr = seg->row_ptr.as<uint32_t>();
     a.news_ptr = seg->news_ptr.as<uint32_t>();
-    a.post_unit = seg->post_unit;
-    a.post_w = seg->post_w;
+    a.post = seg->post;
     a.idf_used = ix->idf_used.as<double>();
     a.url_rank = news ? (ix->has_rank_news ? ix->url_rank_news.as<uint32_t>() : nullptr)
                       : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);

@@ -337,8 +337,7 @@ __device__ __forceinline__ uint32_t tenths24(const RowBits& b, uint64_t r, bool 
 // ------------------------------------------------------------------ posting slots from the last pass ---
 // Outputs of the last sort pass when it writes posting slots (k_sort_scatter_tile<2, true>).
 struct PostOut {
-    uint32_t* post_unit;  // [R + POST_PAD] unit of every sorted row
-    uint32_t* post_w;     // [R + POST_PAD] weight (tenths) at the head of every kept run, POST_HOLE elsewhere
+    Slot* post;           // [R + POST_PAD] unit of every sorted row; weight (tenths) at the head of every kept run, POST_HOLE elsewhere
     uint32_t* news_ptr;   // [n_terms], preset to 0xFFFFFFFF: first news slot of the term (atomic minimum)
     uint32_t* dup;        // [n_terms], zeroed: web rows of the term that are not the head of their run
     uint4* partials;      // [chunks]: kept postings, web heads, kept web postings of the tile
@@ -523,12 +522,7 @@ __device__ __forceinline__ void post_tile(uint64_t* rows_s, const uint32_t* base
                 }
             }
 #endif
-            if (lanes(vm)) {
-#ifndef SEBM25_EXP_ONESTORE
-                po.post_unit[slot] = unit;
-#endif
-                po.post_w[slot] = lanes(km) ? w : POST_HOLE;
-            }
+            if (lanes(vm)) po.post[slot] = make_uint2(unit, lanes(km) ? w : POST_HOLE);
             // weights of 0xFFFF tenths and more do not fit the 16-bit accumulator fields of the stepwise scoring kernels
             big_m |= km & ballot(w >= 0xFFFFu);
             n_kept += (uint32_t)__popcll(km);
@@ -974,10 +968,10 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
 __global__ __launch_bounds__(1024) void k_postings_totals(const uint4* partials, uint32_t n_chunks, unsigned long long* totals);
 
 void launch_sort_scatter_post(const uint64_t* packed, uint64_t R, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                              const unsigned short* prefix, const uint32_t* group_off, uint32_t* post_unit, uint32_t* post_w,
+                              const unsigned short* prefix, const uint32_t* group_off, Slot* post,
                               uint32_t* news_ptr, uint32_t* dup, uint32_t* tmp, uint64_t* totals, hipStream_t st) {
     dim3 grid((G + 7u) / 8u * 8u), block(SORT_THREADS);
-    const PostOut po{post_unit, post_w, news_ptr, dup, reinterpret_cast<uint4*>(tmp)};
+    const PostOut po{post, news_ptr, dup, reinterpret_cast<uint4*>(tmp)};
     hipLaunchKernelGGL((k_sort_scatter_tile<2, true>), grid, block, 0, st, RawRows{}, packed, (uint64_t*)nullptr, R, G, shift, bits,
                        ctx, prefix, group_off, po);
     hipLaunchKernelGGL(k_postings_totals, dim3(1), dim3(1024), 0, st, po.partials, G, reinterpret_cast<unsigned long long*>(totals));
@@ -1147,8 +1141,8 @@ void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStrea
 // what a run head needs to know about the rows behind it (do they continue the run, what do they
 // weigh) then comes from three one-lane shifts of v instead of three more rows to decode.
 __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, uint32_t R, uint32_t chunk_rows,
-                                                          uint32_t n_chunks, RowFmt fmt, uint32_t n_terms, uint32_t* post_unit,
-                                                          uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr,
+                                                          uint32_t n_chunks, RowFmt fmt, uint32_t n_terms, Slot* post,
+                                                          uint32_t* row_ptr, uint32_t* news_ptr,
                                                           uint32_t* df, uint4* partials, uint32_t* err) {
     // the range index is the same for the whole wave: tell the compiler, so that everything derived
     // from it (bounds, base addresses, loop control) lives in scalar registers
@@ -1185,8 +1179,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < RED_ROUNDS; ++j) {
-        post_unit[R + (uint32_t)j * 64u + lane] = 0u;
-        post_w[R + (uint32_t)j * 64u + lane] = POST_HOLE;
+        post[R + (uint32_t)j * 64u + lane] = make_uint2(0xFFFFFFFFu, POST_HOLE);
     }
     asm volatile("" ::: "memory");
 
@@ -1227,8 +1220,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
         if (__ballot(((seen_hi & rb.big_hi) | (seen_lo & rb.big_lo)) != 0u) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
 
         // ---- phase 2: slots, term boundaries, df
-        uint32_t* pu = post_unit + b0;
-        uint32_t* pw = post_w + b0;
+        Slot* ps = post + b0;
         const uint32_t left = end - b0;  // rows of the range from this batch on
 #pragma unroll
         for (int j = 0; j < RED_ROUNDS; ++j) {
@@ -1257,8 +1249,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_postings(const uint64_t* rows, 
             const bool same1 = !(n1 >> 31), same2 = same1 & !(n2 >> 31), same3 = same2 & !(n3 >> 31);
             if (__ballot(kept & same3) && lane == 0) atomicOr(err, DEV_NEED_FIXUP);
             const uint32_t w = (v[j] & 0x7FFFFFFFu) + (same1 ? n1 & 0x7FFFFFFFu : 0u) + (same2 ? n2 & 0x7FFFFFFFu : 0u);
-            pu[li] = unit;
-            pw[li] = kept ? w : POST_HOLE;
+            ps[li] = make_uint2(unit, kept ? w : POST_HOLE);
             // weights of 0xFFFF tenths and more do not fit the 16-bit accumulator fields of the stepwise scoring kernels
             if (__ballot(kept & (w >= 0xFFFFu)) && lane == 0) atomicOr(err, DEV_BIG_WEIGHT);
             n_kept += (uint32_t)__popcll(km);
@@ -1337,9 +1328,9 @@ __global__ __launch_bounds__(1024) void k_postings_totals(const uint4* partials,
 // Exact 64-bit weights for the runs k_postings does not handle in its fast path: more than three
 // rows of one (term, source, unit), or a tf of 2^24 or more.  One thread per row; runs only when
 // k_postings raised DEV_NEED_FIXUP.
-__global__ void k_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err) {
+__global__ void k_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, Slot* post, uint32_t* err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R || post_w[i] == POST_HOLE) return;  // only kept heads carry a weight
+    if (i >= R || post[i].y == POST_HOLE) return;  // only kept heads carry a weight
     const uint64_t x0 = rows[i];
     const bool news = fmt.src(x0) != 0u;
     uint64_t w = 0, n = 0;
@@ -1358,17 +1349,17 @@ __global__ void k_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, u
         atomicOr(err, DEV_ERR_RANGE);
         w = POST_HOLE - 1u;
     }
-    post_w[i] = (uint32_t)w;
+    post[i].y = (uint32_t)w;
     if (w >= 0xFFFFull) atomicOr(err, DEV_BIG_WEIGHT);
 }
 
-void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err, hipStream_t st) {
+void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, Slot* post, uint32_t* err, hipStream_t st) {
     if (R == 0) return;
-    hipLaunchKernelGGL(k_postings_fixup, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, fmt, post_w, err);
+    hipLaunchKernelGGL(k_postings_fixup, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, rows, R, fmt, post, err);
 }
 
 void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt, uint32_t n_terms,
-                     uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df,
+                     Slot* post, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df,
                      uint64_t* totals, uint32_t* tmp, uint32_t* err, hipStream_t st) {
     if (R == 0) return;
     uint4* partials = reinterpret_cast<uint4*>(tmp);  // postings_tmp_words(n_chunks) words
@@ -1376,7 +1367,7 @@ void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint
     const dim3 grid((n_chunks + wpb - 1) / wpb), block(RED_THREADS);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(totals);
     hipLaunchKernelGGL(k_postings, grid, block, 0, st, rows, (uint32_t)R, (uint32_t)chunk_rows, n_chunks, fmt, n_terms,
-                       post_unit, post_w, row_ptr, news_ptr, df, partials, err);
+                       post, row_ptr, news_ptr, df, partials, err);
     hipLaunchKernelGGL(k_postings_totals, dim3(1), dim3(1024), 0, st, partials, n_chunks, tot);
 }
 

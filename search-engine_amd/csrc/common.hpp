@@ -41,6 +41,10 @@ struct RowFmt {
 
 // weight of a posting slot that holds no posting (a merged or filtered row); real weights are smaller
 constexpr uint32_t POST_HOLE = 0xFFFFFFFFu;
+// One posting slot per sorted row: x = the row's unit, y = the posting's weight in tenths at the head of a kept
+// (term, source, unit) run, POST_HOLE elsewhere.  Unit and weight sit side by side so that the pass that makes the
+// slots writes each with one 8-byte store and the scoring kernels read each with one 8-byte load.
+using Slot = uint2;
 
 // device error bits raised by kernels
 // DEV_BIG_WEIGHT: some posting weight does not fit 16 bits (weight + 1 > 0xFFFF): scoring uses the general kernel
@@ -126,10 +130,10 @@ void launch_sort_scatter(int mode, RawRows raw, const uint64_t* packed, uint64_t
                          int bits, const BuildCtx& ctx, const unsigned short* prefix, const uint32_t* group_off,
                          hipStream_t st);
 // the last pass of a two-pass sort on the term bits of unit-major rows, writing posting slots instead of rows:
-// post_unit / post_w [R + POST_PAD], news_ptr preset to 0xFFFFFFFF, dup zeroed (per term: web rows that are not
+// post [R + POST_PAD], news_ptr preset to 0xFFFFFFFF, dup zeroed (per term: web rows that are not
 // run heads), totals [0] kept, [1] web heads, [5] kept web (zeroed), tmp scatter_post_tmp_words(G) words
 void launch_sort_scatter_post(const uint64_t* packed, uint64_t R, uint32_t G, int shift, int bits, const BuildCtx& ctx,
-                              const unsigned short* prefix, const uint32_t* group_off, uint32_t* post_unit, uint32_t* post_w,
+                              const unsigned short* prefix, const uint32_t* group_off, Slot* post,
                               uint32_t* news_ptr, uint32_t* dup, uint32_t* tmp, uint64_t* totals, hipStream_t st);
 size_t scatter_post_tmp_words(uint32_t G);
 // row_ptr[0 .. n_terms] from the offsets of both passes (bin_start1: first input row of every low digit of the
@@ -144,14 +148,14 @@ size_t scan_tmp_words(size_t n);
 void launch_exclusive_scan_u32(uint32_t* data, size_t n, uint32_t* tmp, hipStream_t st);
 
 void launch_postings(const uint64_t* rows, uint64_t R, uint64_t chunk_rows, uint32_t n_chunks, RowFmt fmt, uint32_t n_terms,
-                     uint32_t* post_unit, uint32_t* post_w, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
+                     Slot* post, uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* df /* zeroed */,
                      uint64_t* totals /* [0] kept, [1] web heads, [5] kept web; zeroed */,
                      uint32_t* tmp /* postings_tmp_words(n_chunks) words, 16-byte aligned */, uint32_t* err, hipStream_t st);
 size_t postings_tmp_words(uint32_t n_chunks);
 // fills row_ptr entries of terms without rows (0xFFFFFFFF) and sets row_ptr[n_terms] = R
 size_t row_ptr_fill_tmp_words(uint32_t n_terms);
 void launch_row_ptr_fill(uint32_t* row_ptr, uint32_t n_terms, uint64_t R, uint32_t* tmp, hipStream_t st);
-void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, uint32_t* post_w, uint32_t* err, hipStream_t st);
+void launch_postings_fixup(const uint64_t* rows, uint64_t R, RowFmt fmt, Slot* post, uint32_t* err, hipStream_t st);
 void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows,
                        hipStream_t st);
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
@@ -164,7 +168,7 @@ void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_t
 void launch_bitmap_set(const uint32_t* ids, uint32_t n_ids, uint32_t n, uint32_t shift, uint32_t* bm, hipStream_t st);
 void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipStream_t st);
 void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
-                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, Slot* post, uint32_t* df,
                       uint32_t* term_rows, unsigned long long* counts /* [4] */, hipStream_t st);
 void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
                          uint32_t* err, hipStream_t st);
@@ -198,8 +202,7 @@ constexpr uint32_t SCORE_REG_LISTS = 256;  // lists whose cursors the general ke
 struct ScoreArgs {
     const uint32_t* row_ptr;
     const uint32_t* news_ptr;
-    const uint32_t* post_unit;
-    const uint32_t* post_w;  // posting weights in tenths
+    const Slot* post;  // unit and weight (tenths) of every slot
     const double* idf_used;
     const uint32_t* url_rank;  // may be null
     uint32_t unit_base;

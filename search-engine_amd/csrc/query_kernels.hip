@@ -277,10 +277,10 @@ struct TopK {
 };
 
 // first index in [b, e) whose unit is >= x (per-lane binary search in global memory)
-__device__ __forceinline__ uint32_t lower_bound_unit(const uint32_t* post_unit, uint32_t b, uint32_t e, uint32_t x) {
+__device__ __forceinline__ uint32_t lower_bound_unit(const Slot* post, uint32_t b, uint32_t e, uint32_t x) {
     while (b < e) {
         const uint32_t mid = b + ((e - b) >> 1);
-        if (post_unit[mid] < x) b = mid + 1; else e = mid;
+        if (post[mid].x < x) b = mid + 1; else e = mid;
     }
     return b;
 }
@@ -303,10 +303,11 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         while (true) {
             const uint32_t i = c + lane;
             const bool valid = i < e;
-            const uint32_t u = valid ? a.post_unit[i] : 0xFFFFFFFFu;
+            const Slot sl = valid ? a.post[i] : make_uint2(0xFFFFFFFFu, POST_HOLE);
+            const uint32_t u = sl.x;
             const bool in = valid && (uint64_t)u < wend;
             const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
-            const uint32_t w = in ? a.post_w[i] : POST_HOLE;
+            const uint32_t w = in ? sl.y : POST_HOLE;
             if (w != POST_HOLE) {  // a hole only moves the cursor
                 const double v = __dmul_rn(idf, (double)w);  // idf holds idf / 10, weights are in tenths
                 const uint32_t idx = u - base;
@@ -363,9 +364,9 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
             const uint32_t term = a.q_terms[it.term_off + t];
             const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
             const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-            const uint32_t c = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
+            const uint32_t c = lower_bound_unit(a.post, b, e, it.unit_lo);
             wc[2u * t] = c;
-            wc[2u * t + 1u] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, c, e, it.unit_hi);
+            wc[2u * t + 1u] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post, c, e, it.unit_hi);
         }
         touched[lane] = 0;
         TopK<CAP, true, false, uint32_t> tk;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
             uint32_t nxt = 0xFFFFFFFFu;
             for (uint32_t t = lane; t < T; t += 64u) {
                 const uint32_t c = wc[2u * t], e = wc[2u * t + 1u];
-                if (c < e) nxt = min(nxt, a.post_unit[c]);
+                if (c < e) nxt = min(nxt, a.post[c].x);
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor(nxt, off));
@@ -416,8 +417,8 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
             const uint32_t term = a.q_terms[it.term_off + t];
             const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
             const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-            my_cur[blk] = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
-            my_end[blk] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post_unit, my_cur[blk], e, it.unit_hi);
+            my_cur[blk] = lower_bound_unit(a.post, b, e, it.unit_lo);
+            my_end[blk] = (it.unit_hi == 0xFFFFFFFFu) ? e : lower_bound_unit(a.post, my_cur[blk], e, it.unit_hi);
             my_idf[blk] = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
         }
     }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
         uint32_t nxt = 0xFFFFFFFFu;
 #pragma unroll
         for (int blk = 0; blk < SCORE_LIST_BLOCKS; ++blk)
-            if (my_cur[blk] < my_end[blk]) nxt = min(nxt, a.post_unit[my_cur[blk]]);
+            if (my_cur[blk] < my_end[blk]) nxt = min(nxt, a.post[my_cur[blk]].x);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nxt = min(nxt, (uint32_t)__shfl_xor(nxt, off));
         if (nxt == 0xFFFFFFFFu) break;
@@ -653,8 +654,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         const uint32_t term = a.q_terms[it.term_off + lane];
         const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
         const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
-        my_cur = lower_bound_unit(a.post_unit, b, e, it.unit_lo);
-        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post_unit, my_cur, e, it.unit_hi);
+        my_cur = lower_bound_unit(a.post, b, e, it.unit_lo);
+        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post, my_cur, e, it.unit_hi);
         my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
     }
     // per list: slot index of the current block's first slot, end of the list, the current block (units and
@@ -669,13 +670,13 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     double idf[T];
     auto load_block = [&](int t, uint32_t p, uint32_t lo, uint32_t (&uu)[BM], uint32_t (&ww)[BM]) {
         if (p >= lo && p + 64u * nb(t) <= end[t]) {  // inside the list: no masks
-            const uint32_t* pu = a.post_unit + p;
-            const uint32_t* pw = a.post_w + p;
+            const Slot* ps = a.post + p;
 #pragma unroll
             for (int j = 0; j < BM; ++j) {
                 if (j >= nb(t)) break;
-                uu[j] = pu[64u * j + lane];
-                ww[j] = pw[64u * j + lane];
+                const Slot sl = ps[64u * j + lane];
+                uu[j] = sl.x;
+                ww[j] = sl.y;
             }
         } else {
 #pragma unroll
@@ -683,8 +684,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                 if (j >= nb(t)) break;
                 const uint32_t i = p + 64u * (uint32_t)j + lane;
                 const bool ok = i >= lo && i < end[t];
-                uu[j] = ok ? a.post_unit[i] : INF;
-                ww[j] = ok ? a.post_w[i] : POST_HOLE;
+                const Slot sl = ok ? a.post[i] : make_uint2(INF, POST_HOLE);
+                uu[j] = sl.x;
+                ww[j] = sl.y;
             }
         }
     };

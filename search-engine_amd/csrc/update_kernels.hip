@@ -39,7 +39,7 @@ constexpr int TOMB_BATCH = 8;
 __global__ __launch_bounds__(256) void k_tombstone(const uint64_t* rows, uint32_t R, RowFmt fmt, const uint32_t* chg_web,
                                                    const uint32_t* chg_news, const uint32_t* coarse_g, uint32_t cw,
                                                    uint32_t c_words, uint32_t shift, const uint32_t* dead_web,
-                                                   const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                                                   const uint32_t* dead_news, Slot* post, uint32_t* df,
                                                    uint32_t* term_rows, unsigned long long* counts) {
     extern __shared__ uint32_t coarse[];
     for (uint32_t i = threadIdx.x; i < c_words; i += blockDim.x) coarse[i] = coarse_g[i];
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void k_tombstone(const uint64_t* rows, uint32_
             if (dies) dies = !bit_of(src ? dead_news : dead_web, unit);
             if (dies) {
                 head = !src && (i == 0 || fmt.key(rows[i - 1]) != fmt.key(r[j]));
-                if (post_w[i] != POST_HOLE) {
-                    post_w[i] = POST_HOLE;
+                if (post[i].y != POST_HOLE) {
+                    post[i].y = POST_HOLE;
                     ++c_post;
                     c_web += src ? 0u : 1u;
                 }
@@ -322,11 +322,11 @@ void launch_bitmap_or(uint32_t* dst, const uint32_t* src, uint32_t n_words, hipS
     hipLaunchKernelGGL(k_bitmap_or, dim3((n_words + 255) / 256), dim3(256), 0, st, dst, src, n_words);
 }
 void launch_tombstone(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
-                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, uint32_t* post_w, uint32_t* df,
+                      const uint32_t* coarse, uint32_t cw, uint32_t c_words, uint32_t shift, const uint32_t* dead_web, const uint32_t* dead_news, Slot* post, uint32_t* df,
                       uint32_t* term_rows, unsigned long long* counts, hipStream_t st) {
     if (R == 0) return;
     hipLaunchKernelGGL(k_tombstone, grid_for((R + TOMB_BATCH - 1) / TOMB_BATCH, 256, 4096), dim3(256), (size_t)c_words * 4, st, rows, (uint32_t)R, fmt, chg_web, chg_news, coarse, cw, c_words, shift,
-                       dead_web, dead_news, post_w, df, term_rows, counts);
+                       dead_web, dead_news, post, df, term_rows, counts);
 }
 void launch_check_listed(const uint64_t* rows, uint64_t R, RowFmt fmt, const uint32_t* chg_web, const uint32_t* chg_news,
                          uint32_t* err, hipStream_t st) {
