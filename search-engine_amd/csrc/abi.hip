@@ -402,7 +402,7 @@ int do_finalize(sebm25_index* ix, const uint32_t* df_global, const sebm25_doc_to
     ix->N = ix->used_totals.n_done ? ix->used_totals.n_done : 1;  // `or 1`
     ix->avgdl = ix->used_totals.n_wc ? (double)ix->used_totals.sum_wc / (double)ix->used_totals.n_wc : 0.0;  // `or 0.0`
     phase_begin(ix, "idf");
-    launch_idf(df_dev, ix->V_cur, ix->N, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
+    launch_idf(df_dev, ix->V_cur, ix->N, nullptr, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
     phase_end(ix);
     HIP_TRY(ix, hipGetLastError());
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
@@ -558,14 +558,15 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
             ix->post = reinterpret_cast<Slot*>(dst);
             HIP_TRY(ix, hipMemsetAsync(news_ptr, 0xFF, (size_t)V * 4, ix->stream));
             HIP_TRY(ix, hipMemsetAsync(ix->df_local.p, 0, (size_t)V * 4, ix->stream));
-            HIP_TRY(ix, hipMemsetAsync(ix->post + R, 0xFF, (size_t)POST_PAD * sizeof(Slot), ix->stream));   // what lies behind the last slot reads as holes
+            phase_begin(ix, "first_slots");
+            launch_first_slots(src_packed, R, G, shift, bits_before, bits, ix->bin_start.as<uint32_t>(), prefix, group_off, bin_start,
+                               V, row_ptr, ix->post + R, ix->stream);
+            phase_end(ix);
             phase_begin(ix, "scatter_postings");
             launch_sort_scatter_post(src_packed, R, G, shift, bits, ctx, prefix, group_off, ix->post, news_ptr,
                                      ix->df_local.as<uint32_t>(), ix->scan_tmp.as<uint32_t>(), scal, ix->stream);
             phase_end(ix);
             phase_begin(ix, "term_stats");
-            launch_first_slots(src_packed, R, G, shift, bits_before, bits, ix->bin_start.as<uint32_t>(), prefix, group_off, bin_start,
-                               V, row_ptr, ix->stream);
             launch_term_stats_dup(V, row_ptr, news_ptr, ix->term_rows.as<uint32_t>(), ix->df_local.as<uint32_t>(), ix->stream);
             phase_end(ix);
             HIP_TRY(ix, hipGetLastError());
@@ -593,7 +594,8 @@ int sort_and_post(sebm25_index* ix, RawRows raw, const uint64_t* start_packed, b
 }
 
 // reads the counters a build leaves in ix->scalars, runs the rare exact second look, reports device-side errors
-int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
+int collect_build(sebm25_index* ix, uint64_t (&h)[8], bool* redone = nullptr) {
+    if (redone) *redone = false;
     uint64_t* scal = ix->scalars.as<uint64_t>();
     uint32_t* err_dev = reinterpret_cast<uint32_t*>(scal + 7);
     HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
@@ -609,6 +611,7 @@ int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
         HIP_TRY(ix, hipMemsetAsync(scal + 7, 0, 8, ix->stream));    // device error word
         uint64_t* slots = ix->sorted_rows == ix->sortA.as<uint64_t>() ? ix->sortB.as<uint64_t>() : ix->sortA.as<uint64_t>();
         if ((rc = post_sorted(ix, ix->sorted_rows, slots))) return rc;
+        if (redone) *redone = true;
         HIP_TRY(ix, hipMemcpyAsync(h, scal, 64, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(ix, hipStreamSynchronize(ix->stream));
         dev_err = (uint32_t)(h[7] & 0xFFFFFFFFull);
@@ -633,7 +636,9 @@ int collect_build(sebm25_index* ix, uint64_t (&h)[8]) {
     return SEBM25_OK;
 }
 
-int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
+// and_finalize: the single-GPU job.  idf is queued behind the document totals with N read on the device, so the whole
+// job waits for the GPU once.
+int do_build_local(sebm25_index* ix, const sebm25_rows* in, bool and_finalize = false) {
     if (!in) return fail(ix, SEBM25_E_INVALID, "build: rows is NULL");
     if (in->n_terms == 0) return fail(ix, SEBM25_E_INVALID, "build: n_terms must be >= 1");
     if (in->n_rows > ix->max_rows) return fail(ix, SEBM25_E_RANGE, "build: more than 2^32 - 4096 rows in one shard");
@@ -697,13 +702,28 @@ int do_build_local(sebm25_index* ix, const sebm25_rows* in) {
     phase_end(ix);
     HIP_TRY(ix, hipGetLastError());
 
+    if (and_finalize) {
+        phase_begin(ix, "idf");
+        launch_idf(ix->df_local.as<uint32_t>(), V, 1, scal + 2, ix->idf.as<double>(), ix->idf_used.as<double>(), ix->stream);
+        phase_end(ix);
+        HIP_TRY(ix, hipGetLastError());
+    }
     uint64_t h[8];
-    if ((rc = collect_build(ix, h))) return rc;
+    bool redone = false;
+    if ((rc = collect_build(ix, h, &redone))) return rc;
     ix->local_totals.n_done = h[2];
     ix->local_totals.n_wc = h[3];
     ix->local_totals.sum_wc = h[4];
     ix->local_totals.n_postings = h[0];
     ix->built = true;
+    if (and_finalize) {
+        if (redone) return do_finalize(ix, nullptr, nullptr);   // df was made again by the separate posting pass
+        ix->has_df_global = false;
+        ix->used_totals = ix->local_totals;
+        ix->N = h[2] ? h[2] : 1;                                             // `or 1`
+        ix->avgdl = h[3] ? (double)h[4] / (double)h[3] : 0.0;                // `or 0.0`
+        ix->finalized = true;
+    }
     return SEBM25_OK;
 }
 
@@ -1225,9 +1245,7 @@ int sebm25_build(sebm25_index* ix, const sebm25_rows* rows) {
     if (!ix) return fail(nullptr, SEBM25_E_INVALID, "build: handle is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard g(ix->device);
-    int rc = do_build_local(ix, rows);
-    if (rc) return rc;
-    return do_finalize(ix, nullptr, nullptr);
+    return do_build_local(ix, rows, true);
     ABI_CATCH(ix)
 }
 

@@ -987,7 +987,7 @@ size_t scatter_post_tmp_words(uint32_t G) { return (size_t)G * 4; }
 __global__ __launch_bounds__(256) void k_first_slots(const uint64_t* rows, uint32_t R, uint32_t G, int shift, int bits1, int bits2,
                                                      const uint32_t* bin_start1, const unsigned short* prefix,
                                                      const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
-                                                     uint32_t* row_ptr) {
+                                                     uint32_t* row_ptr, Slot* pad) {
     __shared__ uint32_t hist[SORT_MAX_BINS];
     const uint32_t L = blockIdx.x, nb2 = 1u << bits2;
     for (uint32_t x = threadIdx.x; x < nb2; x += 256u) hist[x] = 0;
@@ -1006,14 +1006,18 @@ __global__ __launch_bounds__(256) void k_first_slots(const uint64_t* rows, uint3
             at = h + 1u < nb2 ? bin_start2[h + 1u] : R;
         row_ptr[t] = at;
     }
-    if (L == 0 && threadIdx.x == 0) row_ptr[n_terms] = R;
+    if (L == 0) {
+        if (threadIdx.x == 0) row_ptr[n_terms] = R;
+        // what lies behind the last slot reads as holes
+        for (uint32_t i = threadIdx.x; i < (uint32_t)POST_PAD; i += 256u) pad[i] = make_uint2(0xFFFFFFFFu, POST_HOLE);
+    }
 }
 
 void launch_first_slots(const uint64_t* rows, uint64_t R, uint32_t G, int shift, int bits1, int bits2, const uint32_t* bin_start1,
                         const unsigned short* prefix, const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
-                        uint32_t* row_ptr, hipStream_t st) {
+                        uint32_t* row_ptr, Slot* pad, hipStream_t st) {
     hipLaunchKernelGGL(k_first_slots, dim3(1u << bits1), dim3(256), 0, st, rows, (uint32_t)R, G, shift, bits1, bits2, bin_start1, prefix,
-                       group_off, bin_start2, n_terms, row_ptr);
+                       group_off, bin_start2, n_terms, row_ptr, pad);
 }
 
 // ------------------------------------------------------------------ exclusive scan --------
@@ -1490,9 +1494,16 @@ void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const
 
 // idf = LN((N - df + 0.5) / (df + 0.5) + 1) (bm25_stats.py:21) as log1p of the quotient, which
 // stays accurate to an ulp when df is close to N (PostgreSQL computes it in NUMERIC).
-__global__ void k_idf(const uint32_t* df, uint32_t n_terms, double N, double* idf, double* idf_used) {
+// n_done_dev: when given, N is read from device memory (the count of 'done' docs a kernel queued before this one
+// left there; 0 reads as 1, bm25_stats.py:13), so that the statistics need no trip to the host in between
+__global__ void k_idf(const uint32_t* df, uint32_t n_terms, double N, const unsigned long long* n_done_dev, double* idf,
+                      double* idf_used) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_terms) return;
+    if (n_done_dev) {
+        const unsigned long long n = *n_done_dev;
+        N = (double)(n ? n : 1ull);
+    }
     const double d = (double)df[t];
     const double q = __ddiv_rn(__dadd_rn(__dadd_rn(N, -d), 0.5), __dadd_rn(d, 0.5));
     const double v = log1p(q);
@@ -1500,8 +1511,10 @@ __global__ void k_idf(const uint32_t* df, uint32_t n_terms, double N, double* id
     idf_used[t] = v;
 }
 
-void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, double* idf, double* idf_used, hipStream_t st) {
-    hipLaunchKernelGGL(k_idf, dim3((n_terms + 255) / 256), dim3(256), 0, st, df, n_terms, (double)N, idf, idf_used);
+void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, const uint64_t* n_done_dev, double* idf, double* idf_used,
+                hipStream_t st) {
+    hipLaunchKernelGGL(k_idf, dim3((n_terms + 255) / 256), dim3(256), 0, st, df, n_terms, (double)N,
+                       reinterpret_cast<const unsigned long long*>(n_done_dev), idf, idf_used);
 }
 
 // idf_used[t] = COALESCE(ts.idf, 1.0) (search_service.py:21,47,86)

@@ -140,7 +140,7 @@ size_t scatter_post_tmp_words(uint32_t G);
 // last pass's input `rows`; prefix / group_off / bin_start2: the last pass's)
 void launch_first_slots(const uint64_t* rows, uint64_t R, uint32_t G, int shift, int bits1, int bits2, const uint32_t* bin_start1,
                         const unsigned short* prefix, const uint32_t* group_off, const uint32_t* bin_start2, uint32_t n_terms,
-                        uint32_t* row_ptr, hipStream_t st);
+                        uint32_t* row_ptr, Slot* pad /* POST_PAD slots behind the last one <- holes */, hipStream_t st);
 void launch_term_stats_dup(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news_ptr, uint32_t* term_rows, uint32_t* df_dup,
                            hipStream_t st);
 // in-place exclusive scan of n uint32 (tmp: at least scan_tmp_words(n) uint32)
@@ -160,7 +160,9 @@ void launch_term_stats(uint32_t n_terms, const uint32_t* row_ptr, uint32_t* news
                        hipStream_t st);
 void launch_doc_stats(const uint32_t* word_count, const uint32_t* doc_len, const uint8_t* doc_flags,
                       uint32_t n_docs, uint64_t* totals3 /* n_done, n_wc, sum_wc (zeroed) */, hipStream_t st);
-void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, double* idf, double* idf_used, hipStream_t st);
+// N from the host, or (n_done_dev != nullptr) from device memory: `n_done or 1`
+void launch_idf(const uint32_t* df, uint32_t n_terms, uint64_t N, const uint64_t* n_done_dev, double* idf, double* idf_used,
+                hipStream_t st);
 void launch_idf_override(const double* idf, const uint8_t* present, uint32_t n_terms, double* idf_used,
                          hipStream_t st);
 
