@@ -431,6 +431,51 @@ def test_tokenizer_known_answers():
     assert porter_stem("by") == "by" and porter_stem("a") == "a"
 
 
+def test_builtin_stemmer_against_published_porter_and_nltk_outputs():
+    """The built-in stemmer against outputs that are in print: the example list of NLTK's PorterStemmer documentation,
+    the Porter-stemmed sentence of the NLTK book (chapter 3), the worked examples of Porter's 1980 paper carried through
+    all steps, and one pair or more for every departure of NLTK's default mode from the paper (irregular-form pool,
+    short words, -ies / -ied after a three-letter stem, the consonant test before a final y, fulli / logi / bli in
+    step 2).  nltk itself is not installed here: still "parity unpinned" against the stemmer the reference's term
+    strings come from, but every rule the two could differ in has a pair below."""
+    nltk_doc = dict(zip("caresses flies dies mules denied died agreed owned humbled sized meeting stating siezing itemization "
+                        "sensational traditional reference colonizer plotted".split(),
+                        "caress fli die mule deni die agre own humbl size meet state siez item sensat tradit refer colon plot".split()))
+    nltk_book = dict(zip("dennis listen strange women lying in ponds distributing swords is no basis for a system of government "
+                         "supreme executive power derives from a mandate from the masses not from some farcical aquatic "
+                         "ceremony".split(),
+                         "denni listen strang women lie in pond distribut sword is no basi for a system of govern suprem execut "
+                         "power deriv from a mandat from the mass not from some farcic aquat ceremoni".split()))
+    paper = {"generalizations": "gener", "oscillators": "oscil", "caress": "caress", "bled": "bled", "tanned": "tan", "fizzed": "fizz",
+             "valenci": "valenc", "hesitanci": "hesit", "conformabli": "conform", "radicalli": "radic", "differentli": "differ",
+             "vileli": "vile", "analogousli": "analog", "predication": "predic", "callousness": "callous", "sensibiliti": "sensibl",
+             "formative": "form", "formalize": "formal", "electriciti": "electr", "hopeful": "hope", "airliner": "airlin",
+             "gyroscopic": "gyroscop", "defensible": "defens", "irritant": "irrit", "adjustment": "adjust", "dependent": "depend",
+             "homologou": "homolog", "activate": "activ", "angulariti": "angular", "homologous": "homolog", "bowdlerize": "bowdler",
+             "probate": "probat", "rational": "ration"}
+    departures = {
+        # the pool of irregular forms
+        "sky": "sky", "skies": "sky", "dying": "die", "lying": "lie", "tying": "tie", "news": "news", "innings": "inning",
+        "inning": "inning", "outings": "outing", "outing": "outing", "cannings": "canning", "canning": "canning", "howe": "howe",
+        "proceed": "proceed", "exceed": "exceed", "succeed": "succeed",
+        # words of one or two letters are left alone
+        "by": "by", "is": "is", "as": "as", "a": "a",
+        # -ies / -ied: "ie" after a one-letter... three-letter word, "i" otherwise
+        "ties": "tie", "lies": "lie", "pies": "pie", "ponies": "poni", "cries": "cri",
+        "tied": "tie", "lied": "lie", "tried": "tri", "spied": "spi", "applied": "appli",
+        # a final y turns into i only behind a consonant (the paper: behind any stem with a vowel: enjoy -> enjoi)
+        "enjoy": "enjoy", "enjoyment": "enjoy", "say": "say", "saying": "say", "fly": "fli", "cry": "cri", "happy": "happi",
+        # step 2: fulli -> ful, logi -> log, bli -> ble
+        "hopefully": "hope", "apology": "apolog", "possibly": "possibl",
+    }
+    n = 0
+    for table in (nltk_doc, nltk_book, paper, departures):
+        for w, stem in table.items():
+            assert porter_stem(w) == stem, (w, stem, porter_stem(w))
+            n += 1
+    assert n >= 120
+
+
 def test_url_ranks():
     r = url_ranks(["https://b", "https://a", "https://c"])
     assert r.tolist() == [1, 0, 2]
