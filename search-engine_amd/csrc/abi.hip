@@ -1581,7 +1581,11 @@ int plan_pass1(sebm25_index* ix, bool news, const uint32_t* q_terms, const uint6
     info.n_flat = (uint32_t)nf;
     // postings per work item: enough items to fill the GPU, few enough that per-item set-up
     // (binary searches, final cut) stays small next to the streaming
-    uint64_t slice = std::min<uint64_t>(std::max<uint64_t>(total_len / 8192, 8192), 524288);
+    static const uint64_t slice_max = [] {
+        const char* e = getenv("SEBM25_EXP_SLICE_MAX");  // experiments only
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : 524288ull;
+    }();
+    uint64_t slice = std::min<uint64_t>(std::max<uint64_t>(total_len / 8192, 8192), slice_max);
     slice = std::max<uint64_t>(slice, (uint64_t)k * 32);
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint64_t n_items = 0, n_tmp = 0;

@@ -628,6 +628,12 @@ __global__ __launch_bounds__(SORT_THREADS, 6) void k_sort_scatter_tile(RawRows r
     const uint32_t per_xcd = (G + 7u) / 8u;
 #ifdef SEBM25_EXP_LINEAR_CHUNKS  // experiment builds only: chunks in dispatch order (what a ticket-ordered one-sweep pass would see)
     const uint32_t chunk = MODE == 2 ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#elif defined(SEBM25_EXP_RUN)  // experiment builds only: the last pass takes runs of SEBM25_EXP_RUN chunks per XCD, interleaved
+    uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (POST) {
+        const uint32_t blk = 8u * SEBM25_EXP_RUN, b = blockIdx.x;
+        chunk = b < (G / blk) * blk ? (b / blk) * blk + (b & 7u) * SEBM25_EXP_RUN + ((b % blk) >> 3) : b;
+    }
 #else
     const uint32_t chunk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 #endif

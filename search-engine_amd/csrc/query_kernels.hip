@@ -152,7 +152,7 @@ struct TopK {
         }
     }
 
-    __device__ void cut(uint32_t k) {
+    __device__ __forceinline__ void cut(uint32_t k) {
         const uint32_t lane = lane_id();
         if (np) {
             // ---- the waiting entries, one per lane, sorted best first across the lanes
@@ -243,7 +243,7 @@ struct TopK {
     }
 
     // every lane may offer one candidate; wave-uniform control flow
-    __device__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
+    __device__ __forceinline__ void offer(bool has, uint64_t ck, uint32_t ct, uint32_t cu, uint32_t cm, uint32_t k) {
         const bool lazy = LAZY_ONLY || (HAS_TIE && lazy_rank != nullptr);
         bool pass = passes(has, lazy, ck, ct);
         uint64_t pm = __ballot(pass);
@@ -1013,6 +1013,348 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
         tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
 }
 
+// ------------------------------------------------------------------------------------------
+// Stepwise scoring by merge join (queries of two to four lists).
+//
+// The same steps as k_score_step (every list holds a block of 64-slot chunks and has the next block in flight;
+// a step takes every slot up to the smallest "last unit of the block" over the lists), but the blocks sit in
+// LDS as sorted arrays of slots and no table is filled.  The lists are taken shortest first.  A posting of the
+// step looks its unit up in the blocks of the longer lists (the chunk by compares with the chunks' last units,
+// which are wave-uniform, then a binary search over its 64 slots: six dependent LDS reads), 64 postings per
+// pass, and has the unit's score at once, summed in the order the caller gave the terms in.  Every slot found
+// that way is turned into a hole in LDS, so the longer list's own turn skips it: a unit is scored once, by
+// the shortest list that holds it, and nothing ever searches a shorter list.
+//  * Lists other than the shortest (of three or four) are filtered before they search: a posting whose unit no
+//    shorter list held is worth a search only if its own part plus the most the longer lists can add (idf x
+//    the largest weight of their current blocks, which hold every posting of the step) reaches the k-th best
+//    score.  What passes is compacted into a work list first, so the passes run with most lanes busy.  A unit
+//    dropped there scores below the k-th best whatever the longer lists hold for it; the part of it that a
+//    longer list may offer later is smaller still and is rejected against the score of that moment, which only
+//    rises.  This needs every idf of the query to be positive and is switched off otherwise.
+//  * The longest list, most of the postings, is only tested against the smallest weight with which a posting
+//    that no other list shares could reach the k-th best score.
+//  * A block keeps the slots before the list's cursor as {0, hole} and the slots behind its end as
+//    {0xFFFFFFFF, hole}: it stays sorted, and first_idx (non-zero in a list's first block only) keeps a search
+//    for unit 0 off the former.  A hole never matches: the first slot of a unit's run carries the weight
+//    when the run has one.
+template <int N>
+__device__ __forceinline__ uint32_t join_lower_bound(const Slot* b, uint32_t p, uint32_t x) {
+    if constexpr (N > 1) {
+        constexpr int H = N / 2;
+        p += b[p + (uint32_t)(H - 1)].x < x ? (uint32_t)H : 0u;
+        return join_lower_bound<N - H>(b, p, x);
+    } else {
+        return p;
+    }
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int T, class TK, bool HAS_RANK, int WAVES_PER_SIMD, int B, int BL>
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) {
+    static_assert(T >= 2 && T <= 4, "two to four lists");
+    constexpr uint32_t INF = 0xFFFFFFFFu;
+    constexpr int BM = B > BL ? B : BL;
+    auto nb = [](int t) constexpr { return t == T - 1 ? BL : B; };          // chunks per block
+    auto off = [](int t) constexpr { return (uint32_t)(64 * B * t); };       // first slot of the list's block
+    __shared__ __align__(16) Slot blk[64 * (B * (T - 1) + BL)];
+    __shared__ unsigned short wk[64 * B];                                    // slots of a list's block that take part in the step
+    __shared__ __align__(16) unsigned char topk_mem[TK::bytes()];
+
+    const QItem it = a.items[blockIdx.x];
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    auto ballot = [](bool c) { return (uint64_t)__builtin_amdgcn_ballot_w64(c); };
+    auto lanes = [](uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
+
+    uint32_t my_cur = 0, my_end = 0;
+    double my_idf = 0.0;
+    if (lane < (uint32_t)T) {
+        const uint32_t term = a.q_terms[it.term_off + lane];
+        const uint32_t b = a.news ? a.news_ptr[term] : a.row_ptr[term];
+        const uint32_t e = a.news ? a.row_ptr[term + 1] : a.news_ptr[term];
+        my_cur = lower_bound_unit(a.post, b, e, it.unit_lo);
+        my_end = (it.unit_hi == INF) ? e : lower_bound_unit(a.post, my_cur, e, it.unit_hi);
+        my_idf = __ddiv_rn(a.idf_used[term], 10.0);  // weights are stored in tenths
+    }
+    uint32_t pos[T], end[T];       // slot index of the current block's first slot, end of the list
+    uint32_t s[T], first_idx[T];   // first slot of the block not yet taken; first slot of the block inside the list's range
+    uint32_t cl[T][BM];            // unit of the last slot of every chunk of the block
+    uint32_t maxw[T];              // largest weight in the block
+    uint32_t nu[T][BM], nw[T][BM]; // the block in flight
+    auto load_block = [&](auto tc, uint32_t p, uint32_t lo) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        if (p >= lo && p + 64u * nb(t) <= end[t]) {  // inside the list: no masks
+            const Slot* ps = a.post + p;
+#pragma unroll
+            for (int j = 0; j < nb(t); ++j) {
+                const Slot sl = ps[64u * j + lane];
+                nu[t][j] = sl.x;
+                nw[t][j] = sl.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < nb(t); ++j) {
+                const uint32_t i = p + 64u * (uint32_t)j + lane;
+                const bool behind = i >= end[t], ok = i >= lo && !behind;
+                const Slot sl = ok ? a.post[i] : make_uint2(behind ? INF : 0u, POST_HOLE);
+                nu[t][j] = sl.x;
+                nw[t][j] = sl.y;
+            }
+        }
+    };
+    // the first list that is filtered: with more than two lists the shortest one searches for every posting (filtering
+    // it as well changed nothing: 12.9 -> 13.2 ms per 10k three-term queries over the 10M-doc index)
+    constexpr int FIRST_F = T == 2 ? 0 : 1;
+    // the block in flight becomes the current one
+    auto take_block = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        int32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < nb(t); ++j) {
+            blk[off(t) + 64u * (uint32_t)j + lane] = make_uint2(nu[t][j], nw[t][j]);
+            cl[t][j] = (uint32_t)__builtin_amdgcn_readlane((int)nu[t][j], 63);
+            if (t > FIRST_F) mx = max(mx, (int32_t)nw[t][j]);  // a hole reads as -1 (weights here are below 2^31)
+        }
+        if (t > FIRST_F) {
+            uint32_t v = (uint32_t)mx;
+            v = max(v, lane_xor<1>(v));
+            v = max(v, lane_xor<2>(v));
+            v = max(v, lane_xor<4>(v));
+            v = max(v, lane_xor<8>(v));
+            v = max(v, lane_xor<16>(v));
+            maxw[t] = max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 32));
+        }
+    };
+    // idf[j], pl[j]: idf of the term the caller gave at position j and the list it became
+    double idf[T];
+    uint32_t pl[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        pl[j] = sfirst((it.order >> (3 * j)) & 7u);
+        idf[j] = readlane_f64(my_idf, (int)pl[j]);
+    }
+    const double idf_last = readlane_f64(my_idf, T - 1);
+    double idf_p[T], inv_idf_p[T];  // idf of the lists as they sit
+    bool all_positive = true;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        idf_p[t] = readlane_f64(my_idf, t);
+        all_positive = all_positive && idf_p[t] > 0.0 && idf_p[t] < 1e300;
+        inv_idf_p[t] = 1.0 / idf_p[t];
+        maxw[t] = 0;
+    }
+    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)my_cur, t);
+        end[t] = (uint32_t)__builtin_amdgcn_readlane((int)my_end, t);
+        pos[t] = cur & ~63u;
+        if (cur >= end[t]) {  // empty list: nothing to read
+            pos[t] = 0;
+            end[t] = 0;
+        }
+        s[t] = first_idx[t] = cur >= end[t] ? 0u : cur - pos[t];
+        load_block(tc, pos[t], cur);
+    });
+    static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        take_block(tc);
+        load_block(tc, pos[t] + 64u * nb(t), 0u);
+    });
+    TK tk;
+    tk.init(topk_mem);
+    constexpr bool LAZY = HAS_RANK && TK::CAN_LAZY;
+    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base);
+    uint32_t w_min = 0;
+    double thr_seen = tk.thr_score;
+    uint32_t F_prev = 0;
+    bool first_step = true;
+    __builtin_amdgcn_wave_barrier();
+#ifdef SEBM25_EXP_STATS
+    uint32_t st_steps = 0, st_ins = 0, st_rounds = 0, st_offers = 0, st_passes = 0;
+#endif
+
+    auto offer = [&](uint64_t may_m, double sc, uint32_t unit, uint32_t m) __attribute__((always_inline)) {
+        const bool may = lanes(may_m);
+        uint32_t tie = 0;
+        if (may && !LAZY) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
+        tk.offer(may, score_key(sc), tie, unit + a.unit_base, m, a.k);
+    };
+
+    while (true) {
+        uint32_t F = cl[0][nb(0) - 1];
+#pragma unroll
+        for (int t = 1; t < T; ++t) F = min(F, cl[t][nb(t) - 1]);
+        const bool final_step = F == INF;  // every list is in its last block: take what is left
+        const uint32_t Fc = min(F, INF - 1u);
+
+        // smallest weight with which a posting of a filtered list is looked at
+        uint32_t w_mid[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) w_mid[t] = 0;
+        {
+            const double thr = tk.thr_score;
+            if (all_positive && thr > 0.0) {
+                double ub = 0.0;
+#pragma unroll
+                for (int t = T - 2; t >= FIRST_F; --t) {
+                    ub += idf_p[t + 1] * (double)maxw[t + 1];
+                    const double x = (thr * (1.0 - 1e-12) - ub) * inv_idf_p[t];
+                    w_mid[t] = x < 2.0 ? 0u : (x >= 2147483648.0 ? 0x7FFFFFFFu : (uint32_t)x - 1u);
+                }
+            }
+        }
+
+        // ---- the lists but the longest, shortest first
+        static_for<0, T - 1>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            // the slots of the step that still hold a posting worth a search, compacted
+            uint32_t n = 0;
+#pragma unroll
+            for (int c = 0; c < nb(t); ++c) {
+                if (s[t] >= 64u * (uint32_t)(c + 1)) continue;  // taken by earlier steps
+                const uint32_t idx = 64u * (uint32_t)c + lane;
+                const Slot me = blk[off(t) + idx];
+                const uint64_t in_m = ballot(me.x <= Fc);
+                uint64_t keep = in_m & ballot(me.y + 1u > w_mid[t]);  // (a hole wraps to 0)
+                if (s[t] > 64u * (uint32_t)c) keep &= ~0ull << (s[t] - 64u * (uint32_t)c);
+                if (keep) {
+                    if (lanes(keep)) wk[n + (uint32_t)__popcll(keep & lt)] = (unsigned short)idx;
+                    n += (uint32_t)__popcll(keep);
+                }
+                s[t] = 64u * (uint32_t)c + (uint32_t)__popcll(in_m);
+                if (cl[t][c] > Fc) break;
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef SEBM25_EXP_STATS
+            st_ins += n;
+#endif
+            for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+#ifdef SEBM25_EXP_STATS
+                ++st_passes;
+#endif
+                const bool has = i0 + lane < n;
+                const uint32_t idx = has ? wk[i0 + lane] : 0u;
+                const Slot me = blk[off(t) + idx];
+                uint32_t wt[T];
+                static_for<0, T>([&](auto oc) __attribute__((always_inline)) {
+                    constexpr int o = decltype(oc)::value;
+                    if constexpr (o < t) {
+                        wt[o] = POST_HOLE;  // a shorter list that held the unit would have taken this slot
+                    } else if constexpr (o == t) {
+                        wt[o] = me.y;
+                    } else {
+                        uint32_t c0 = 0;  // the chunk: units beyond a chunk's last unit lie in a later one
+#pragma unroll
+                        for (int j = 0; j + 1 < nb(o); ++j) c0 += me.x > cl[o][j] ? 64u : 0u;
+                        const Slot* b = blk + off(o);
+                        const uint32_t p = max(join_lower_bound<64>(b + c0, 0u, me.x) + c0, first_idx[o]);
+                        const Slot r = b[p];
+                        const bool found = has && r.x == me.x && r.y != POST_HOLE;
+                        wt[o] = found ? r.y : POST_HOLE;
+                        if (found) blk[off(o) + p].y = POST_HOLE;  // taken: the list's own turn skips it
+                    }
+                });
+                double sc = 0.0;
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {  // the order the caller gave the terms in
+                    uint32_t w = wt[0];
+#pragma unroll
+                    for (int l = 1; l < T; ++l) w = pl[j] == (uint32_t)l ? wt[l] : w;
+                    if (w != POST_HOLE) {
+                        const double v = __dmul_rn(idf[j], (double)w);
+                        sc = m ? __dadd_rn(sc, v) : v;
+                        ++m;
+                    }
+                }
+                const uint64_t may_m = ballot(has) & ballot(sc >= tk.thr_score);
+#ifdef SEBM25_EXP_STATS
+                st_offers += (uint32_t)__popcll(may_m);
+#endif
+                if (may_m) offer(may_m, sc, me.x, m);
+            }
+            __builtin_amdgcn_wave_barrier();
+        });
+
+        // ---- the longest list: what is left of it in this step belongs to units that no other list holds
+        {
+            constexpr int t = T - 1;
+#pragma unroll
+            for (int c = 0; c < BL; ++c) {
+                if (!first_step && cl[t][c] <= F_prev) continue;  // taken by earlier steps
+                const Slot me = blk[off(t) + 64u * (uint32_t)c + lane];
+                uint64_t may_m = ballot(me.y + 1u > w_min);  // (a hole wraps to 0)
+                if (may_m) {
+                    may_m &= ballot(me.x <= Fc);
+                    if (!first_step) may_m &= ~ballot(me.x <= F_prev);
+                    const double sc = __dmul_rn(idf_last, (double)me.y);
+                    may_m &= ballot(sc >= tk.thr_score);
+#ifdef SEBM25_EXP_STATS
+                    st_rounds += (uint32_t)__popcll(may_m);
+#endif
+                    if (may_m) offer(may_m, sc, me.x, 1u);
+                }
+                if (cl[t][c] > Fc) break;
+            }
+        }
+#ifdef SEBM25_EXP_STATS
+        ++st_steps;
+#endif
+        if (final_step) break;
+        first_step = false;
+        F_prev = Fc;
+        if (tk.thr_score != thr_seen) {  // the k-th best score rose: what the longest list must now bring alone
+            thr_seen = tk.thr_score;
+            w_min = 0;
+            if (idf_last > 0.0 && thr_seen > 0.0) {
+                const double x = thr_seen / idf_last;
+                if (x >= 2147483648.0) {
+                    w_min = 0x7FFFFFFFu;  // above every weight
+                } else {
+                    w_min = (uint32_t)x;
+                    w_min = w_min > 1u ? w_min - 2u : 0u;
+                    while (__dmul_rn(idf_last, (double)w_min) < thr_seen) ++w_min;  // exact: the product formed above
+                }
+            }
+        }
+        // ---- lists whose block is used up: the block in flight becomes the current one, the one behind it is requested
+        static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if (cl[t][nb(t) - 1] <= Fc) {
+                take_block(tc);
+                pos[t] += 64u * nb(t);
+                load_block(tc, pos[t] + 64u * nb(t), 0u);
+                s[t] = 0;
+                first_idx[t] = 0;
+            }
+        });
+        __builtin_amdgcn_wave_barrier();
+    }
+
+#ifdef SEBM25_EXP_STATS  // steps, passes, postings that searched, offers of the longest list, other offers, items
+    if (lane == 0) {
+        atomicAdd(&g_step_stats[0], (unsigned long long)st_steps);
+        atomicAdd(&g_step_stats[1], (unsigned long long)st_passes);
+        atomicAdd(&g_step_stats[2], (unsigned long long)st_ins);
+        atomicAdd(&g_step_stats[3], (unsigned long long)st_rounds);
+        atomicAdd(&g_step_stats[4], (unsigned long long)st_offers);
+        atomicAdd(&g_step_stats[5], 1ull);
+    }
+#endif
+    const size_t o = (size_t)it.out_slot * a.k;
+    if (it.direct)
+        tk.write_out(a.k, a.out_unit + o, a.out_score + o, a.out_matched + o, a.out_tie ? a.out_tie + o : nullptr,
+                     a.out_count + it.out_slot);
+    else
+        tk.write_out(a.k, a.tmp_unit + o, a.tmp_score + o, a.tmp_matched + o, a.tmp_tie + o, a.tmp_count + it.out_slot);
+}
+
 // one wave per query: merges n[q] result lists (each best-first, <= k entries) into one
 template <int CAP>
 __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
@@ -1077,8 +1419,62 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, BLK_MID, 512>), grid, block, 0, st, b);
 }
+// Chunks per block of the merge-join kernels: (lists but the longest, longest list).  Longer blocks mean fewer steps
+// and fuller passes, more LDS per wave means fewer waves: 10k three-term queries over the 10M-doc index, k = 10 /
+// k = 210: (2, 4) 13.7 / 21.7 ms, (2, 6) 14.0 / 19.8, (2, 8) 13.1 / 20.5, (4, 8) 12.1 / 20.1.
+#ifndef SEBM25_JOIN_BLOCK
+#define SEBM25_JOIN_BLOCK 4
+#endif
+#ifndef SEBM25_JOIN_BLOCK_L
+#define SEBM25_JOIN_BLOCK_L 8
+#endif
+#ifndef SEBM25_JOIN_BLOCK_MID
+#define SEBM25_JOIN_BLOCK_MID 2
+#endif
+#ifndef SEBM25_JOIN_BLOCK_MID_L
+#define SEBM25_JOIN_BLOCK_MID_L 6
+#endif
+#ifndef SEBM25_JOIN_WAVES
+#define SEBM25_JOIN_WAVES 6
+#endif
+#ifndef SEBM25_JOIN_WAVES_MID
+#define SEBM25_JOIN_WAVES_MID 4
+#endif
+template <int T, bool HAS_RANK>
+static void launch_join_t(const ScoreArgs& b, hipStream_t st) {
+    dim3 grid(b.n_items), block(64);
+    constexpr int BLK = SEBM25_JOIN_BLOCK, BLK_L = SEBM25_JOIN_BLOCK_L, BM = SEBM25_JOIN_BLOCK_MID, BM_L = SEBM25_JOIN_BLOCK_MID_L;
+    constexpr int W = SEBM25_JOIN_WAVES, WM = SEBM25_JOIN_WAVES_MID;
+    if (b.k <= 48)
+        hipLaunchKernelGGL((k_score_join<T, RegTopK<HAS_RANK>, HAS_RANK, W, BLK, BLK_L>), grid, block, 0, st, b);
+    else if (b.k <= 128)
+        hipLaunchKernelGGL((k_score_join<T, TopK<192, HAS_RANK, HAS_RANK>, HAS_RANK, WM, BM, BM_L>), grid, block, 0, st, b);
+    else if (b.k <= 256)
+        hipLaunchKernelGGL((k_score_join<T, TopK<304, HAS_RANK, HAS_RANK>, HAS_RANK, WM, BM, BM_L>), grid, block, 0, st, b);
+    else if (b.k <= 512)
+        hipLaunchKernelGGL((k_score_join<T, TopK<576, HAS_RANK, HAS_RANK>, HAS_RANK, 2, 2, 4>), grid, block, 0, st, b);
+    else if (b.k <= 1024)
+        hipLaunchKernelGGL((k_score_join<T, TopK<1088, HAS_RANK, HAS_RANK>, HAS_RANK, 2, 2, 4>), grid, block, 0, st, b);
+    else
+        hipLaunchKernelGGL((k_score_join<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, 2, 4>), grid, block, 0, st, b);
+}
+// SEBM25_JOIN=0 in the environment sends queries of two to four lists to the table kernels (k_score_step) instead:
+// for comparisons
+static bool use_join() {
+    static const bool on = [] {
+        const char* e = getenv("SEBM25_JOIN");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 template <int T>
 static void launch_step(const ScoreArgs& b, hipStream_t st) {
+    if constexpr (T >= 2 && T <= 4) {
+        if (use_join()) {
+            if (b.url_rank) launch_join_t<T, true>(b, st); else launch_join_t<T, false>(b, st);
+            return;
+        }
+    }
     if (b.url_rank) launch_step_t<T, true>(b, st); else launch_step_t<T, false>(b, st);
 }
 
