@@ -450,8 +450,8 @@ def main():
         tq = traffic_db.get("query", {})
         if tq.get("postings_scored_per_batch") == sum_df:
             q_traffic = tq.get("hbm_bytes_per_launch")
-        kq = ("k_score_step<3, RegTopK<false>, false, 6, 2, 512, 4>" if args.k <= 48 else
-              "k_score_step<3, TopK<192, false, false>, false, 3, 2, 512, 3>" if args.k <= 128 else "k_score_step<3, TopK<304, false, false>, false, 3, 2, 512, 4>")
+        kq = ("k_score_join<3, RegTopK<false>, false, 6, 4, 8>" if args.k <= 48 else
+              "k_score_join<3, TopK<192, false, false>, false, 4, 3, 8>" if args.k <= 128 else "k_score_join<3, TopK<304, false, false>, false, 4, 3, 8>")
         out["query"] = {
             "metric": f"top{args.k}_queries_per_s", "value": args.queries / (q_ms * 1e-3), "unit": "queries/s",
             "ms_per_batch": q_ms, "queries": args.queries, "terms_per_query": args.terms_per_query, "k": args.k,

@@ -1037,16 +1037,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
 //    {0xFFFFFFFF, hole}: it stays sorted, and first_idx (non-zero in a list's first block only) keeps a search
 //    for unit 0 off the former.  A hole never matches: the first slot of a unit's run carries the weight
 //    when the run has one.
-template <int N>
-__device__ __forceinline__ uint32_t join_lower_bound(const Slot* b, uint32_t p, uint32_t x) {
-    if constexpr (N > 1) {
-        constexpr int H = N / 2;
-        p += b[p + (uint32_t)(H - 1)].x < x ? (uint32_t)H : 0u;
-        return join_lower_bound<N - H>(b, p, x);
-    } else {
-        return p;
-    }
-}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -1241,7 +1231,33 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
                 const bool has = i0 + lane < n;
                 const uint32_t idx = has ? wk[i0 + lane] : 0u;
                 const Slot me = blk[off(t) + idx];
-                uint32_t wt[T];
+                // the searches in the longer lists run side by side: every round issues its reads before the first compare
+                uint32_t wt[T], sp[T];
+                static_for<t + 1, T>([&](auto oc) __attribute__((always_inline)) {
+                    constexpr int o = decltype(oc)::value;
+                    uint32_t c0 = 0;  // the chunk: units beyond a chunk's last unit lie in a later one
+#pragma unroll
+                    for (int j = 0; j + 1 < nb(o); ++j) c0 += me.x > cl[o][j] ? 64u : 0u;
+                    sp[o] = off(o) + c0;
+                });
+#pragma unroll
+                for (int h = 32; h >= 1; h >>= 1) {  // lower bound over the chunk's 64 slots
+                    uint32_t v[T];
+                    static_for<t + 1, T>([&](auto oc) __attribute__((always_inline)) {
+                        constexpr int o = decltype(oc)::value;
+                        v[o] = blk[sp[o] + (uint32_t)(h - 1)].x;
+                    });
+                    static_for<t + 1, T>([&](auto oc) __attribute__((always_inline)) {
+                        constexpr int o = decltype(oc)::value;
+                        sp[o] += v[o] < me.x ? (uint32_t)h : 0u;
+                    });
+                }
+                Slot r[T];
+                static_for<t + 1, T>([&](auto oc) __attribute__((always_inline)) {
+                    constexpr int o = decltype(oc)::value;
+                    sp[o] = max(sp[o], off(o) + first_idx[o]);
+                    r[o] = blk[sp[o]];
+                });
                 static_for<0, T>([&](auto oc) __attribute__((always_inline)) {
                     constexpr int o = decltype(oc)::value;
                     if constexpr (o < t) {
@@ -1249,15 +1265,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
                     } else if constexpr (o == t) {
                         wt[o] = me.y;
                     } else {
-                        uint32_t c0 = 0;  // the chunk: units beyond a chunk's last unit lie in a later one
-#pragma unroll
-                        for (int j = 0; j + 1 < nb(o); ++j) c0 += me.x > cl[o][j] ? 64u : 0u;
-                        const Slot* b = blk + off(o);
-                        const uint32_t p = max(join_lower_bound<64>(b + c0, 0u, me.x) + c0, first_idx[o]);
-                        const Slot r = b[p];
-                        const bool found = has && r.x == me.x && r.y != POST_HOLE;
-                        wt[o] = found ? r.y : POST_HOLE;
-                        if (found) blk[off(o) + p].y = POST_HOLE;  // taken: the list's own turn skips it
+                        const bool found = has && r[o].x == me.x && r[o].y != POST_HOLE;
+                        wt[o] = found ? r[o].y : POST_HOLE;
+                        if (found) blk[sp[o]].y = POST_HOLE;  // taken: the list's own turn skips it
                     }
                 });
                 double sc = 0.0;
@@ -1420,19 +1430,15 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
     hipLaunchKernelGGL((k_score_step<T, TopK<2112, HAS_RANK, HAS_RANK>, HAS_RANK, 1, BLK_MID, 512>), grid, block, 0, st, b);
 }
 // Chunks per block of the merge-join kernels: (lists but the longest, longest list).  Longer blocks mean fewer steps
-// and fuller passes, more LDS per wave means fewer waves: 10k three-term queries over the 10M-doc index, k = 10 /
-// k = 210: (2, 4) 13.7 / 21.7 ms, (2, 6) 14.0 / 19.8, (2, 8) 13.1 / 20.5, (4, 8) 12.1 / 20.1.
+// and fuller passes, more LDS per wave means fewer waves.  10k three-term queries over the 10M-doc index, k = 10 /
+// k = 210, before the searches of a pass ran side by side: (2, 4) 13.7 / 21.7 ms, (2, 6) 14.0 / 19.8, (2, 8) 13.1 / 20.5,
+// (4, 8) 12.1 / 20.1, (2, 12) 13.9 / -, (2, 16) 15.7 / -; with them: (4, 8) 11.7 at k = 10, (3, 8) 18.0 and (2, 6) 18.7
+// at k = 210 (four lists at k = 210: 42.8 against 41.2 ms per batch, so those keep (2, 6)).
 #ifndef SEBM25_JOIN_BLOCK
 #define SEBM25_JOIN_BLOCK 4
 #endif
 #ifndef SEBM25_JOIN_BLOCK_L
 #define SEBM25_JOIN_BLOCK_L 8
-#endif
-#ifndef SEBM25_JOIN_BLOCK_MID
-#define SEBM25_JOIN_BLOCK_MID 2
-#endif
-#ifndef SEBM25_JOIN_BLOCK_MID_L
-#define SEBM25_JOIN_BLOCK_MID_L 6
 #endif
 #ifndef SEBM25_JOIN_WAVES
 #define SEBM25_JOIN_WAVES 6
@@ -1443,7 +1449,7 @@ static void launch_step_t(const ScoreArgs& b, hipStream_t st) {
 template <int T, bool HAS_RANK>
 static void launch_join_t(const ScoreArgs& b, hipStream_t st) {
     dim3 grid(b.n_items), block(64);
-    constexpr int BLK = SEBM25_JOIN_BLOCK, BLK_L = SEBM25_JOIN_BLOCK_L, BM = SEBM25_JOIN_BLOCK_MID, BM_L = SEBM25_JOIN_BLOCK_MID_L;
+    constexpr int BLK = SEBM25_JOIN_BLOCK, BLK_L = SEBM25_JOIN_BLOCK_L, BM = T == 4 ? 2 : 3, BM_L = T == 4 ? 6 : 8;
     constexpr int W = SEBM25_JOIN_WAVES, WM = SEBM25_JOIN_WAVES_MID;
     if (b.k <= 48)
         hipLaunchKernelGGL((k_score_join<T, RegTopK<HAS_RANK>, HAS_RANK, W, BLK, BLK_L>), grid, block, 0, st, b);
