@@ -4,13 +4,15 @@
 //   ORDER BY score DESC, url ASC LIMIT k.
 //
 // One wavefront owns one work item = (query, range of unit ids).  A term's posting list is a range of
-// slots sorted by unit (a few of them holes that carry no posting).  Queries of up to eight lists take the
-// stepwise kernel (k_score_step): all lists advance together to a common frontier, 64 coalesced slots per
-// list per load, integer accumulators in a small LDS hash table, and the best k in registers (small k) or in
-// an LDS buffer that is merged, not re-sorted, when it fills.  Longer queries take the general kernel
-// (k_score), which walks windows of WIN consecutive unit ids with directly indexed accumulators.  Lists are
-// always added in query-term order, so a score is the same double sum whatever the work split.  No
-// workgroup barriers: a wave's LDS operations complete in issue order.
+// slots sorted by unit (a few of them holes that carry no posting).  All lists of a query advance together
+// to a common frontier, 64 coalesced slots per list per load.  Queries of two to four lists take the
+// merge-join kernel (k_score_join): the lists' blocks sit in LDS as sorted arrays and a posting finds its
+// unit's other postings by binary search.  Queries of one list and of five to eight lists take the table
+// kernel (k_score_step): integer accumulators in a small LDS hash table.  Both keep the best k in registers
+// (small k) or in an LDS buffer that is merged, not re-sorted, when it fills.  Longer queries take the
+// general kernel (k_score), which walks windows of WIN consecutive unit ids with directly indexed
+// accumulators.  Lists are always added in query-term order, so a score is the same double sum whatever the
+// work split.  No workgroup barriers: a wave's LDS operations complete in issue order.
 #include "common.hpp"
 
 namespace sebm25 {
