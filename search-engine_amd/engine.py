@@ -110,8 +110,27 @@ class SearchEngine:
         """Brings the index (and term_statistics) to the state a rebuild would give after the crawler replaced,
         removed or added the given documents (documents.id) and news articles (url): their current rows are
         read from the database, everything the index held for them is dropped (app/crawler/worker.py:229-239,
-        app/batch/news_fetcher.py:303-311).  Only these units' rows cross to the GPU."""
+        app/batch/news_fetcher.py:303-311).  Only these units' rows cross to the GPU.
+
+        The export's dictionaries (doc positions, terms, url ranks) are extended before the index takes the rows.  If
+        anything fails between the two, export and index would describe different id spaces: the engine then rebuilds
+        from the database (the state a rebuild gives is what an update has to reach anyway) and raises the failure.
+
+        Where an update and a rebuild differ: token rows whose document or article row is gone (orphans) are dropped
+        here and not counted, while a rebuild counts them (a tokens-only doc id is a doc that is not done and counts
+        in df; rows of a vanished article go to the extra term rows).  The reference's writers delete a unit's tokens
+        together with the unit, so the two agree on what they write; the next rebuild reconciles the rest."""
         self.ensure_ready()
+        self._update_dirty = False
+        try:
+            return self._update(doc_ids, article_urls, write_back)
+        except Exception:
+            if self._update_dirty:
+                self._pos_of = None
+                self.rebuild(write_back=write_back)
+            raise
+
+    def _update(self, doc_ids, article_urls, write_back):
         with self._build_lock:
             ex, ix = self.export, self.index
             data = self.store.export_units(ex, doc_ids, article_urls)
@@ -126,6 +145,7 @@ class SearchEngine:
             doc_pos, art_pos = self._doc_pos, self._art_pos
             with self._lock:
                 # ---- documents: position of each changed id (new ids go to the end), columns as they are now
+                self._update_dirty = True
                 n_old = len(ex.doc_ids)
                 new_ids, new_wc, new_fl, new_urls = [], [], [], []
                 set_wc, set_fl, url_changes = {}, {}, {}
@@ -207,6 +227,7 @@ class SearchEngine:
                 ix.update(np.asarray(t_l, np.uint32), np.asarray(u_l, np.uint32), np.asarray(f_l, np.uint32),
                           np.asarray(m_l, np.uint8), ex.n_terms, ex.n_docs, ex.n_articles, ex.word_count, ex.doc_flags,
                           changed_docs=changed_docs, changed_articles=changed_arts)
+                self._update_dirty = False
                 # explicit ranks only once a unit's index is no longer its place in url order (docs or articles were
                 # appended, a url changed): until then ties break on the index and searches skip the rank gather
                 if ex.n_docs and not self._doc_ranker.identity:

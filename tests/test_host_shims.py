@@ -534,6 +534,42 @@ def test_engine_update_on_cpu_stand_in(tmp_path):
     check_engine_update(tmp_path, OracleBackedIndex)
 
 
+def test_engine_update_that_fails_in_the_index_rebuilds_from_the_database(tmp_path):
+    """The export's dictionaries are extended before the index takes the rows; when the index refuses them the engine
+    must not go on with an export and an index that describe different id spaces: it rebuilds and raises."""
+    path = str(tmp_path / "se.db")
+    make_db(path)
+    store = SqlStore(lambda: sqlite3.connect(path))
+
+    class FailingOnce(OracleBackedIndex):
+        fail = True
+
+        def update(self, *a, **kw):
+            if FailingOnce.fail:
+                FailingOnce.fail = False
+                raise RuntimeError("index refused the update")
+            return super().update(*a, **kw)
+
+    engine = SearchEngine(store, index_factory=FailingOnce)
+    engine.rebuild()
+    first_export = engine.export
+    db = sqlite3.connect(path)
+    db.execute("INSERT INTO documents VALUES (40,'https://aaa.example/first','Sorting radix keys','','radix sort keys quantum',4,'done')")
+    for term, freq in tokenize("radix sort keys quantum").items():
+        db.execute("INSERT INTO tokens VALUES (40,?,4,?,NULL,1)", (term, freq))
+    db.commit()
+    db.close()
+    with pytest.raises(RuntimeError, match="refused"):
+        engine.update(doc_ids=[40])
+    assert engine.export is not first_export            # rebuilt: export and index are one snapshot again
+    for terms in (["radix", "sort"], ["quantum"]):
+        rows, ref = engine.score_web(terms, 50), sql_reference_rows(path, terms, 50)
+        assert [r[:3] for r in rows] == [r[:3] for r in ref], terms
+    engine.update(doc_ids=[40])                          # and updates work again
+    rows, ref = engine.score_web(["quantum"], 50), sql_reference_rows(path, ["quantum"], 50)
+    assert [r[:3] for r in rows] == [r[:3] for r in ref]
+
+
 @pytest.mark.gpu
 def test_engine_update_on_gpu(tmp_path):
     engine = check_engine_update(tmp_path, None)
