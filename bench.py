@@ -417,7 +417,8 @@ def main():
         sum_df = int(df_local.astype(np.int64)[qs.reshape(-1)].sum())
 
         def run_queries(k, steps, with_rank=True):
-            q_ix.set_url_rank(se.SRC_WEB, ident if with_rank else None)
+            # (through the sharded index when there is one: the exchange carries tie-break keys only when ranks are set)
+            (q_sharded if q_sharded is not None else q_ix).set_url_rank(se.SRC_WEB, ident if with_rank else None)
             res = {key: torch.empty((args.queries, k), dtype=dt, device=dev) for key, dt in
                    (("unit", torch.int32), ("score", torch.float64), ("matched", torch.int32), ("tie", torch.int32))}
             res["count"] = torch.empty(args.queries, dtype=torch.int32, device=dev)
@@ -457,8 +458,9 @@ def main():
             "ms_per_batch": q_ms, "queries": args.queries, "terms_per_query": args.terms_per_query, "k": args.k,
             "workload": (f"10k x 3-term batch over a {q_docs}-doc index on one GPU (benchmark configuration 4, one-GPU leg), "
                          f"ties broken on the unit id (docs numbered in url order)" if world == 1 else
-                         f"10k x 3-term batch over {q_docs} docs per GPU x {world} GPUs: local top-k, all-gather, merge on "
-                         f"every rank (benchmark configuration 4, {world}-GPU leg when the shards add up to 10M docs)"),
+                         f"10k x 3-term batch over {q_docs} docs per GPU x {world} GPUs: local top-k, all-to-all of the lists by query "
+                         f"partition, merge of 1/{world} of the queries per rank, all-gather of the merged rows (benchmark configuration 4, "
+                         f"{world}-GPU leg when the shards add up to 10M docs)"),
             "index_rows_per_gpu": int(q_rows), "postings_scored_per_batch_per_gpu": sum_df,
             "roofline": {"bound": "hbm", "achieved": alg_q / (score_ms * 1e-3) / 1e9 if score_ms else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
