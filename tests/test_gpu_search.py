@@ -161,7 +161,9 @@ def test_sliced_long_queries_equal_unsliced(gpu_index_factory):
     ix = gpu_index_factory()
     gpu_build(ix, c)
     ix.set_idf(orc.idf)
-    qs = np.array([[0, 1, 2], [3, 9, 700], [5, 6, 2999]], np.uint32)
+    # one to five lists: every stepwise kernel form with work items that start inside their lists
+    qs = [np.array(q, np.uint32) for q in ([0, 1, 2], [3, 9, 700], [5, 6, 2999], [0, 1], [4, 2500], [0, 1, 2, 3], [8, 7, 1500, 2998],
+                                           [2], [0, 3, 5, 7, 11])]
     for k in (10, 300, 700):
         out = ix.search(qs, k)
         for qi, q in enumerate(qs):
