@@ -1334,6 +1334,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
 #ifdef SEBM25_EXP_STATS
                 st_ins += n;
 #endif
+#ifdef SEBM25_EXP_NOPASS  // experiment builds only (wrong results): what the steps cost without the searches
+                n = 0;
+#endif
                 for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
 #ifdef SEBM25_EXP_STATS
                     ++st_passes;
@@ -1408,6 +1411,9 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
             constexpr int t = T - 1;
 #pragma unroll
             for (int c = 0; c < BL; ++c) {
+#ifdef SEBM25_EXP_NOLONG  // experiment builds only (wrong results): without the longest list's test
+                break;
+#endif
                 if (!first_step && cl[t][c] <= F_prev) continue;  // taken by earlier steps
                 const Slot me = blk[off(t) + 64u * (uint32_t)c + lane];
                 uint64_t may_m = ballot(me.y + 1u > w_min);  // (a hole wraps to 0)
