@@ -34,14 +34,18 @@ async def run() -> None:
     await asyncio.to_thread(_engine.rebuild)
 
 
-async def run_incremental(doc_ids=(), article_urls=()) -> None:
-    """The job for a known set of changes: the documents (documents.id) and news articles (url) the crawler
-    and the news fetcher wrote since the last run.  Same effect on term_statistics and on searches as run(),
-    without reading the whole `tokens` table again."""
+async def run_incremental(doc_ids=None, article_urls=None) -> None:
+    """The job for the changes since the last run: the documents (documents.id) and news articles (url) the crawler
+    and the news fetcher wrote.  Same effect on term_statistics and on searches as run(), without reading the
+    whole `tokens` table again.  Without arguments the changes come from the change-capture triggers
+    (SqlStore.install_change_capture); with arguments, from the caller."""
     global _engine
     if _engine is None:
         _engine = _default_engine()
-    await asyncio.to_thread(_engine.update, list(doc_ids), list(article_urls))
+    if doc_ids is None and article_urls is None:
+        await asyncio.to_thread(_engine.update_pending)
+    else:
+        await asyncio.to_thread(_engine.update, list(doc_ids or ()), list(article_urls or ()))
 
 
 if __name__ == "__main__":

@@ -130,6 +130,19 @@ class SearchEngine:
                 self.rebuild(write_back=write_back)
             raise
 
+    def update_pending(self, write_back: bool = True):
+        """update() for whatever the change-capture triggers listed since the last call (SqlStore.install_change_capture):
+        the statistics job without reading the whole `tokens` table and without being told what changed.  -> the
+        statistics, or None when nothing was written.  A run that fails lists its units again."""
+        docs, arts = self.store.drain_changes()
+        if not docs and not arts:
+            return None
+        try:
+            return self.update(docs, arts, write_back=write_back)
+        except Exception:
+            self.store.note_changes(docs, arts)
+            raise
+
     def _update(self, doc_ids, article_urls, write_back):
         with self._build_lock:
             ex, ix = self.export, self.index

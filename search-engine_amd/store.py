@@ -554,6 +554,105 @@ class SqlStore:
             conn.close()
         return out
 
+    # ---- change capture: which units were written since the job last ran
+    CHANGE_TABLE = "sebm25_changed_units"
+    _SQLITE_CAPTURE = (
+        "CREATE TABLE IF NOT EXISTS sebm25_changed_units (doc_id INTEGER, article_url TEXT)",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_tok_ins AFTER INSERT ON tokens BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NEW.doc_id, NEW.article_url); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_tok_del AFTER DELETE ON tokens BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (OLD.doc_id, OLD.article_url); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_tok_upd AFTER UPDATE ON tokens BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (OLD.doc_id, OLD.article_url), (NEW.doc_id, NEW.article_url); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_doc_ins AFTER INSERT ON documents BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NEW.id, NULL); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_doc_upd AFTER UPDATE ON documents BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NEW.id, NULL); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_doc_del AFTER DELETE ON documents BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (OLD.id, NULL); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_art_ins AFTER INSERT ON news_articles BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NULL, NEW.url); END",
+        "CREATE TRIGGER IF NOT EXISTS sebm25_art_del AFTER DELETE ON news_articles BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NULL, OLD.url); END",
+    )
+    # PostgreSQL: statement-level triggers with transition tables, so a crawl that writes a few hundred token rows of one
+    # document logs one row.  (This text has not run here: there is no PostgreSQL server in the build image.)
+    _POSTGRES_CAPTURE = (
+        "CREATE TABLE IF NOT EXISTS sebm25_changed_units (doc_id BIGINT, article_url TEXT)",
+        "CREATE OR REPLACE FUNCTION sebm25_note_new_tokens() RETURNS trigger LANGUAGE plpgsql AS $$ BEGIN "
+        "INSERT INTO sebm25_changed_units SELECT DISTINCT doc_id, article_url FROM changed; RETURN NULL; END $$",
+        "CREATE OR REPLACE FUNCTION sebm25_note_doc() RETURNS trigger LANGUAGE plpgsql AS $$ BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (COALESCE(NEW.id, OLD.id), NULL); RETURN NULL; END $$",
+        "CREATE OR REPLACE FUNCTION sebm25_note_article() RETURNS trigger LANGUAGE plpgsql AS $$ BEGIN "
+        "INSERT INTO sebm25_changed_units VALUES (NULL, COALESCE(NEW.url, OLD.url)); RETURN NULL; END $$",
+        "DROP TRIGGER IF EXISTS sebm25_tok_ins ON tokens",
+        "CREATE TRIGGER sebm25_tok_ins AFTER INSERT ON tokens REFERENCING NEW TABLE AS changed "
+        "FOR EACH STATEMENT EXECUTE FUNCTION sebm25_note_new_tokens()",
+        "DROP TRIGGER IF EXISTS sebm25_tok_del ON tokens",
+        "CREATE TRIGGER sebm25_tok_del AFTER DELETE ON tokens REFERENCING OLD TABLE AS changed "
+        "FOR EACH STATEMENT EXECUTE FUNCTION sebm25_note_new_tokens()",
+        "DROP TRIGGER IF EXISTS sebm25_tok_upd ON tokens",
+        "CREATE TRIGGER sebm25_tok_upd AFTER UPDATE ON tokens REFERENCING NEW TABLE AS changed "
+        "FOR EACH STATEMENT EXECUTE FUNCTION sebm25_note_new_tokens()",
+        "DROP TRIGGER IF EXISTS sebm25_doc_any ON documents",
+        "CREATE TRIGGER sebm25_doc_any AFTER INSERT OR UPDATE OR DELETE ON documents FOR EACH ROW EXECUTE FUNCTION sebm25_note_doc()",
+        "DROP TRIGGER IF EXISTS sebm25_art_any ON news_articles",
+        "CREATE TRIGGER sebm25_art_any AFTER INSERT OR DELETE ON news_articles FOR EACH ROW EXECUTE FUNCTION sebm25_note_article()",
+    )
+
+    def install_change_capture(self):
+        """Adds (idempotently) a table that lists the units whose token rows, status, word count or url were written,
+        kept current by triggers on tokens / documents / news_articles.  The reference's writers need no change: the
+        crawler replaces a document's token rows inside its own transaction (app/crawler/worker.py:229-239) and the news
+        fetcher an article's (app/batch/news_fetcher.py:303-311); the triggers see both."""
+        conn = self._connect()
+        try:
+            cur = conn.cursor()
+            for stmt in (self._POSTGRES_CAPTURE if self.postgres else self._SQLITE_CAPTURE):
+                cur.execute(stmt)
+            conn.commit()
+        finally:
+            conn.close()
+
+    def drain_changes(self):
+        """-> (doc ids, article urls) written since the last drain, and forgets them, in one transaction: a unit written
+        while the drained ones are being processed is listed again for the next run."""
+        conn = self._connect()
+        try:
+            cur = conn.cursor()
+            if self.postgres:
+                cur.execute("DELETE FROM sebm25_changed_units RETURNING doc_id, article_url")
+                rows = cur.fetchall()
+            else:
+                try:
+                    cur.execute("BEGIN IMMEDIATE")
+                except Exception:  # noqa: BLE001 - a driver that already opened the transaction
+                    pass
+                cur.execute("SELECT doc_id, article_url FROM sebm25_changed_units")
+                rows = cur.fetchall()
+                cur.execute("DELETE FROM sebm25_changed_units")
+            conn.commit()
+        except Exception:
+            conn.rollback()
+            raise
+        finally:
+            conn.close()
+        docs = list(dict.fromkeys(int(d) for d, _ in rows if d is not None))
+        arts = list(dict.fromkeys(u for _, u in rows if u is not None))
+        return docs, arts
+
+    def note_changes(self, doc_ids=(), article_urls=()):
+        """Lists units as changed (what a failed run puts back)."""
+        conn = self._connect()
+        try:
+            cur = conn.cursor()
+            p = self._p
+            cur.executemany(f"INSERT INTO sebm25_changed_units VALUES ({p},{p})",
+                            [(int(d), None) for d in doc_ids] + [(None, u) for u in article_urls])
+            conn.commit()
+        finally:
+            conn.close()
+
     # ---- write back
     def write_term_statistics(self, terms, df, idf, avgdl, term_rows, extra_term_rows=None) -> int:
         """TRUNCATE + INSERT in one transaction: readers see the old table or the new one
