@@ -1202,9 +1202,11 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
             }
         }
 
-        // Three shorter lists: one work list for all of them and passes that take 64 of its postings whatever their lists
-        // (10k four-term queries, k = 210: 34.9 against 41.8 ms per batch).  One or two: a list at a time, so that the second
-        // list's passes search one list, not two (three-term queries, k = 210: 17.7 against 18.9 ms).
+        // Three shorter lists (four-list queries): one work list for all of them and passes that take 64 of its postings
+        // whatever their lists, every lane searching every list but the shortest (10k queries, k = 210: 34.9 against 41.8 ms
+        // per batch with a list at a time).  Two shorter lists: that form was slower than a list at a time (k = 210: 18.9
+        // against 17.7 ms: the second list's passes then search two lists instead of one); what pays is to let postings of the
+        // second list ride in the lanes that the shortest list's last pass leaves free (16.2 ms; k = 10: 11.6 -> 11.3 ms).
         if constexpr (T >= 4) {
             // ---- the lists but the longest: the slots of the step that still hold a posting worth a search, compacted
             //      (shortest list first)
@@ -1309,8 +1311,158 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
                 if (may_m) offer(may_m, sc, mx, m);
             }
             __builtin_amdgcn_wave_barrier();
+        } else if constexpr (T == 3) {
+            // ---- three lists: the postings of the shortest list search both longer lists; the lanes they leave free in their
+            //      last pass take postings of the second list along (those only use what the longest list returns); what is
+            //      left of the second list's postings then takes passes of its own, which search one list
+            unsigned char* wkb = reinterpret_cast<unsigned char*>(wk);
+            constexpr uint32_t HALF = 64u * (uint32_t)B;
+            static_assert(HALF <= 256u, "slot indices of a block fit a byte");
+            uint32_t nn[2] = {0, 0};
+            static_for<0, 2>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
+#pragma unroll
+                for (int c = 0; c < nb(t); ++c) {
+                    if (s[t] >= 64u * (uint32_t)(c + 1)) continue;  // taken by earlier steps
+                    const uint32_t idx = 64u * (uint32_t)c + lane;
+                    const Slot me = blk[off(t) + idx];
+                    const uint64_t in_m = ballot(me.x <= Fc);
+                    uint64_t keep = in_m & ballot(me.y + 1u > w_mid[t]);  // (a hole wraps to 0)
+                    if (s[t] > 64u * (uint32_t)c) keep &= ~0ull << (s[t] - 64u * (uint32_t)c);
+                    if (keep) {
+                        if (lanes(keep)) wkb[(uint32_t)t * HALF + nn[t] + (uint32_t)__popcll(keep & lt)] = (unsigned char)idx;
+                        nn[t] += (uint32_t)__popcll(keep);
+                    }
+                    s[t] = 64u * (uint32_t)c + (uint32_t)__popcll(in_m);
+                    if (cl[t][c] > Fc) break;
+                }
+            });
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n0 = nn[0], n1 = nn[1];
+#ifdef SEBM25_EXP_STATS
+            st_ins += n0 + n1;
+#endif
+            uint32_t rode = 0;  // postings of the second list that went along with the shortest list's
+            for (uint32_t i0 = 0; i0 < n0; i0 += 64u) {
+#ifdef SEBM25_EXP_STATS
+                ++st_passes;
+#endif
+                const uint32_t take0 = min(n0 - i0, 64u);
+                const uint32_t riders = i0 + 64u >= n0 ? min(n1, 64u - take0) : 0u;
+                const bool has = lane < take0 + riders;
+                const uint32_t tl = lane < take0 ? 0u : 1u;
+                const uint32_t at = tl == 0u ? i0 + lane : HALF + lane - take0;
+                const uint32_t gi = has ? (tl == 0u ? off(0) : off(1)) + wkb[at] : 0u;
+                const Slot me = blk[gi];
+                const uint32_t mx = me.x, my = me.y;
+                bool act = has && my != POST_HOLE;
+                uint32_t sp[T];
+                static_for<1, T>([&](auto oc) __attribute__((always_inline)) {
+                    constexpr int o = decltype(oc)::value;
+                    uint32_t c0 = 0;  // the chunk: units beyond a chunk's last unit lie in a later one
+#pragma unroll
+                    for (int j = 0; j + 1 < nb(o); ++j) c0 += mx > cl[o][j] ? 64u : 0u;
+                    sp[o] = off(o) + c0;
+                });
+#pragma unroll
+                for (int h = 32; h >= 1; h >>= 1) {  // lower bound over the chunk's 64 slots, both lists side by side
+                    uint32_t v[T];
+                    static_for<1, T>([&](auto oc) __attribute__((always_inline)) {
+                        constexpr int o = decltype(oc)::value;
+                        v[o] = blk[sp[o] + (uint32_t)(h - 1)].x;
+                    });
+                    static_for<1, T>([&](auto oc) __attribute__((always_inline)) {
+                        constexpr int o = decltype(oc)::value;
+                        sp[o] += v[o] < mx ? (uint32_t)h : 0u;
+                    });
+                }
+                uint32_t rx[T], ry[T];
+                static_for<1, T>([&](auto oc) __attribute__((always_inline)) {
+                    constexpr int o = decltype(oc)::value;
+                    sp[o] = max(sp[o], off(o) + first_idx[o]);
+                    const Slot r = blk[sp[o]];
+                    rx[o] = r.x;
+                    ry[o] = r.y;
+                });
+                const bool found1 = act && tl == 0u && rx[1] == mx && ry[1] != POST_HOLE;
+                if (found1) blk[sp[1]].y = POST_HOLE;  // taken: the second list's postings skip it
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t now = blk[gi].y;        // a posting of the second list that went along: taken just now?
+                if (tl == 1u && now == POST_HOLE) act = false;
+                const bool found2 = act && rx[2] == mx && ry[2] != POST_HOLE;
+                if (found2) blk[sp[2]].y = POST_HOLE;  // taken: the longest list's own test skips it
+                uint32_t wt[T];
+                wt[0] = tl == 0u ? my : POST_HOLE;
+                const uint32_t w1 = found1 ? ry[1] : POST_HOLE;
+                wt[1] = tl == 1u ? my : w1;
+                wt[2] = found2 ? ry[2] : POST_HOLE;
+                double sc = 0.0;
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {  // the order the caller gave the terms in
+                    uint32_t w = wt[0];
+#pragma unroll
+                    for (int l = 1; l < T; ++l) w = pl[j] == (uint32_t)l ? wt[l] : w;
+                    if (w != POST_HOLE) {
+                        const double v = __dmul_rn(idf[j], (double)w);
+                        sc = m ? __dadd_rn(sc, v) : v;
+                        ++m;
+                    }
+                }
+                const uint64_t may_m = ballot(act) & ballot(sc >= tk.thr_score);
+#ifdef SEBM25_EXP_STATS
+                st_offers += (uint32_t)__popcll(may_m);
+#endif
+                if (may_m) offer(may_m, sc, mx, m);
+                rode += riders;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = rode; i0 < n1; i0 += 64u) {
+#ifdef SEBM25_EXP_STATS
+                ++st_passes;
+#endif
+                const bool has = i0 + lane < n1;
+                const uint32_t gi = off(1) + (has ? wkb[HALF + i0 + lane] : 0u);
+                const Slot me = blk[gi];
+                const uint32_t mx = me.x, my = me.y;
+                const bool act = has && my != POST_HOLE;  // (the shortest list's postings may have taken it meanwhile)
+                constexpr int o = 2;
+                uint32_t sp = off(o);
+#pragma unroll
+                for (int j = 0; j + 1 < nb(o); ++j) sp += mx > cl[o][j] ? 64u : 0u;
+#pragma unroll
+                for (int h = 32; h >= 1; h >>= 1) sp += blk[sp + (uint32_t)(h - 1)].x < mx ? (uint32_t)h : 0u;
+                sp = max(sp, off(o) + first_idx[o]);
+                const Slot r = blk[sp];
+                const uint32_t rx = r.x, ry = r.y;
+                const bool found = act && rx == mx && ry != POST_HOLE;
+                if (found) blk[sp].y = POST_HOLE;
+                uint32_t wt[T];
+                wt[0] = POST_HOLE;
+                wt[1] = my;
+                wt[2] = found ? ry : POST_HOLE;
+                double sc = 0.0;
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    uint32_t w = wt[0];
+#pragma unroll
+                    for (int l = 1; l < T; ++l) w = pl[j] == (uint32_t)l ? wt[l] : w;
+                    if (w != POST_HOLE) {
+                        const double v = __dmul_rn(idf[j], (double)w);
+                        sc = m ? __dadd_rn(sc, v) : v;
+                        ++m;
+                    }
+                }
+                const uint64_t may_m = ballot(act) & ballot(sc >= tk.thr_score);
+#ifdef SEBM25_EXP_STATS
+                st_offers += (uint32_t)__popcll(may_m);
+#endif
+                if (may_m) offer(may_m, sc, mx, m);
+            }
+            __builtin_amdgcn_wave_barrier();
         } else {
-            // ---- the lists but the longest, shortest first
+            // ---- two lists: the postings of the shorter one, 64 per pass (the general form: a list at a time, shortest first)
             static_for<0, T - 1>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
                 // the slots of the step that still hold a posting worth a search, compacted
