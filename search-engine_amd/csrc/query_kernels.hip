@@ -1558,28 +1558,40 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
             });
         }
 
-        // ---- the longest list: what is left of it in this step belongs to units that no other list holds
+        // ---- the longest list: what is left of it in this step belongs to units that no other list holds.  First the
+        //      weights of the whole block against the smallest weight that could matter (nearly always none passes, and one
+        //      scalar test ends the matter); which slots are in the step at all is only looked at for chunks that have one.
         {
             constexpr int t = T - 1;
+            uint64_t wm[BL];
+            uint64_t any_m = 0;
+            {
+                uint32_t wv[BL];
 #pragma unroll
-            for (int c = 0; c < BL; ++c) {
-#ifdef SEBM25_EXP_NOLONG  // experiment builds only (wrong results): without the longest list's test
-                break;
-#endif
-                if (!first_step && cl[t][c] <= F_prev) continue;  // taken by earlier steps
-                const Slot me = blk[off(t) + 64u * (uint32_t)c + lane];
-                uint64_t may_m = ballot(me.y + 1u > w_min);  // (a hole wraps to 0)
-                if (may_m) {
-                    may_m &= ballot(me.x <= Fc);
-                    if (!first_step) may_m &= ~ballot(me.x <= F_prev);
-                    const double sc = __dmul_rn(idf_last, (double)me.y);
-                    may_m &= ballot(sc >= tk.thr_score);
-#ifdef SEBM25_EXP_STATS
-                    st_rounds += (uint32_t)__popcll(may_m);
-#endif
-                    if (may_m) offer(may_m, sc, me.x, 1u);
+                for (int c = 0; c < BL; ++c) wv[c] = blk[off(t) + 64u * (uint32_t)c + lane].y;
+#pragma unroll
+                for (int c = 0; c < BL; ++c) {
+                    wm[c] = ballot(wv[c] + 1u > w_min);  // (a hole wraps to 0)
+                    any_m |= wm[c];
                 }
-                if (cl[t][c] > Fc) break;
+            }
+            if (any_m) {
+#pragma unroll
+                for (int c = 0; c < BL; ++c) {
+                    if (!first_step && cl[t][c] <= F_prev) continue;  // taken by earlier steps
+                    if (wm[c]) {
+                        const Slot me = blk[off(t) + 64u * (uint32_t)c + lane];
+                        uint64_t may_m = wm[c] & ballot(me.x <= Fc);
+                        if (!first_step) may_m &= ~ballot(me.x <= F_prev);
+                        const double sc = __dmul_rn(idf_last, (double)me.y);
+                        may_m &= ballot(sc >= tk.thr_score);
+#ifdef SEBM25_EXP_STATS
+                        st_rounds += (uint32_t)__popcll(may_m);
+#endif
+                        if (may_m) offer(may_m, sc, me.x, 1u);
+                    }
+                    if (cl[t][c] > Fc) break;
+                }
             }
         }
 #ifdef SEBM25_EXP_STATS
