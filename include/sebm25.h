@@ -164,6 +164,16 @@ int sebm25_set_idf(sebm25_index* ix, const double* idf, const uint8_t* present);
  * `source` is SEBM25_SRC_WEB or SEBM25_SRC_NEWS; rank has n_docs or n_articles entries. */
 int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank);
 
+/* The same keys without an array for the units that kept their place in url order (no counterpart in the
+ * reference, whose ORDER BY reads the urls): for an index whose first n_base units of `source` were numbered in
+ * url order (as the export does at a rebuild) and whose later units were appended by updates.  Unit u < n_base gets
+ * the key (u + 1) << shift, unit n_base + i the key keys[i] (host or device array, n_keys = units - n_base entries):
+ * a unit appended between the urls of base units j and j + 1 takes a key in ((j + 1) << shift, (j + 2) << shift),
+ * one before the first base unit a key in [1, 1 << shift).  Searches then read a key from memory only for the
+ * appended units.  (n_base + 1) << shift must fit 32 bits, shift <= 16; SEBM25_E_RANGE otherwise. */
+int sebm25_set_url_rank_appended(sebm25_index* ix, int source, uint32_t n_base, uint32_t shift, const uint32_t* keys,
+                                 uint32_t n_keys);
+
 /* Added to local unit ids in search results (document-sharded indexes). */
 int sebm25_set_unit_base(sebm25_index* ix, uint32_t web_base, uint32_t news_base);
 

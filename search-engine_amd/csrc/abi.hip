@@ -60,6 +60,7 @@ struct sebm25_index {
     DevBuf st_term, st_unit, st_tf, st_meta, st_wc, st_flags, st_misc;
     DevBuf url_rank_web, url_rank_news;
     bool has_rank_web = false, has_rank_news = false, has_df_global = false;
+    uint32_t rank_base_web = 0, rank_shift_web = 0, rank_base_news = 0, rank_shift_news = 0;  // units whose key needs no array
     Slot* post = nullptr;  // one slot per sorted row: unit, weight in tenths (or POST_HOLE)
     const uint64_t* sorted_rows = nullptr;  // the sorted packed rows this segment was built from (read again by updates)
     // A build whose last sort pass wrote the posting slots has no sorted rows: the input of that pass (the
@@ -1366,7 +1367,36 @@ int sebm25_set_url_rank(sebm25_index* ix, int source, const uint32_t* rank) {
     HIP_TRY(ix, buf.ensure(std::max<size_t>(n, 1) * 4));
     HIP_TRY(ix, hipMemcpyAsync(buf.p, rank, n * 4, hipMemcpyDefault, ix->stream));
     HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    (web ? ix->rank_base_web : ix->rank_base_news) = 0;
+    (web ? ix->rank_shift_web : ix->rank_shift_news) = 0;
     has = true;
+    return SEBM25_OK;
+    ABI_CATCH(ix)
+}
+
+int sebm25_set_url_rank_appended(sebm25_index* ix, int source, uint32_t n_base, uint32_t shift, const uint32_t* keys,
+                                 uint32_t n_keys) {
+    ABI_TRY
+    if (!ix) return fail(nullptr, SEBM25_E_INVALID, "set_url_rank_appended: handle is NULL");
+    if (source != (int)SEBM25_SRC_WEB && source != (int)SEBM25_SRC_NEWS)
+        return fail(ix, SEBM25_E_INVALID, "set_url_rank_appended: source must be 1 (web) or 2 (news)");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!ix->built) return fail(ix, SEBM25_E_STATE, "set_url_rank_appended: no index built on this handle");
+    const bool web = source == (int)SEBM25_SRC_WEB;
+    const size_t n = web ? ix->n_docs_cur : ix->n_articles_cur;
+    if ((size_t)n_base + n_keys != n)
+        return fail(ix, SEBM25_E_INVALID, "set_url_rank_appended: n_base + n_keys must be the number of units");
+    if (n_keys && !keys) return fail(ix, SEBM25_E_INVALID, "set_url_rank_appended: keys is NULL");
+    if (shift > 16 || (((uint64_t)n_base + 1) << shift) > 0xFFFFFFFFull)
+        return fail(ix, SEBM25_E_RANGE, "set_url_rank_appended: (n_base + 1) << shift must fit 32 bits, shift <= 16");
+    DevBuf& buf = web ? ix->url_rank_web : ix->url_rank_news;
+    HIP_TRY(ix, buf.ensure(std::max<size_t>(n_keys, 1) * 4));
+    if (n_keys) HIP_TRY(ix, hipMemcpyAsync(buf.p, keys, (size_t)n_keys * 4, hipMemcpyDefault, ix->stream));
+    HIP_TRY(ix, hipStreamSynchronize(ix->stream));
+    (web ? ix->rank_base_web : ix->rank_base_news) = n_base;
+    (web ? ix->rank_shift_web : ix->rank_shift_news) = shift;
+    (web ? ix->has_rank_web : ix->has_rank_news) = true;
     return SEBM25_OK;
     ABI_CATCH(ix)
 }
@@ -1685,6 +1715,8 @@ ScoreArgs score_args_of(const sebm25_index* ix, const sebm25_index* seg, bool ne
     a.idf_used = ix->idf_used.as<double>();
     a.url_rank = news ? (ix->has_rank_news ? ix->url_rank_news.as<uint32_t>() : nullptr)
                       : (ix->has_rank_web ? ix->url_rank_web.as<uint32_t>() : nullptr);
+    a.rank_base = news ? ix->rank_base_news : ix->rank_base_web;
+    a.rank_shift = news ? ix->rank_shift_news : ix->rank_shift_web;
     a.unit_base = news ? ix->news_base : ix->web_base;
     a.news = news ? 1 : 0;
     a.items = b.items;

@@ -207,6 +207,9 @@ struct ScoreArgs {
     const Slot* post;  // unit and weight (tenths) of every slot
     const double* idf_used;
     const uint32_t* url_rank;  // may be null
+    // tie-break key of unit u when url_rank is set: u < rank_base ? (u + 1) << rank_shift : url_rank[u - rank_base]
+    // (rank_base = 0: url_rank holds a key for every unit)
+    uint32_t rank_base, rank_shift;
     uint32_t unit_base;
     int news;  // 0 web, 1 news
     const QItem* items;

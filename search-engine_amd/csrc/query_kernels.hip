@@ -39,6 +39,12 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t ta, uint64_t kb, ui
     return ka > kb || (ka == kb && ta < tb);
 }
 
+// Tie-break key of a unit when keys were given (sebm25_set_url_rank / sebm25_set_url_rank_appended): the first `base`
+// units kept their place in url order and need no array (key (unit + 1) << shift), the others read theirs.
+__device__ __forceinline__ uint32_t rank_key(const uint32_t* rank, uint32_t base, uint32_t shift, uint32_t unit) {
+    return unit < base ? (unit + 1u) << shift : rank[unit - base];
+}
+
 // value of lane (l ^ MASK): lane-exchange forms that stay in the vector pipeline where the hardware has one
 // (quad permutes, row mirrors), a swizzle for the 16 / 31 patterns, the LDS crossbar only across the wave halves
 template <uint32_t MASK>
@@ -89,16 +95,22 @@ struct TopK {
     // takes no key (it lets every candidate in whose score reaches the k-th best) and cut() reads the keys of the
     // waiting candidates in one go: one memory latency per 64 candidates instead of one per offer.
     const uint32_t* lazy_rank;
-    uint32_t lazy_base;
+    uint32_t lazy_base;                   // global id of the index's first unit
+    uint32_t lazy_kbase, lazy_kshift;     // units that need no array (rank_key)
     static constexpr bool CAN_LAZY = HAS_TIE;
-    __device__ void set_lazy_ties(const uint32_t* rank, uint32_t base) {
+    __device__ void set_lazy_ties(const uint32_t* rank, uint32_t base, uint32_t kbase, uint32_t kshift) {
         lazy_rank = rank;
         lazy_base = base;
+        lazy_kbase = kbase;
+        lazy_kshift = kshift;
+    }
+    __device__ __forceinline__ uint32_t lazy_key(uint32_t global_unit) const {
+        return rank_key(lazy_rank, lazy_kbase, lazy_kshift, global_unit - lazy_base);
     }
 
     __device__ void init(unsigned char* lds) {
         lazy_rank = nullptr;
-        lazy_base = 0;
+        lazy_base = lazy_kbase = lazy_kshift = 0;
         key = reinterpret_cast<uint64_t*>(lds);
         unit = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);
         tie_ = unit + CAP;
@@ -124,7 +136,7 @@ struct TopK {
 #endif
     // LAZY_ONLY keeps no tie-break keys at all: a key is the rank of the entry's unit, read when two scores tie
     // (and once per cut for the k-th best); a dead entry ranks behind everything
-    __device__ __forceinline__ uint32_t tie_of_unit(uint32_t u) const { return u == 0xFFFFFFFFu ? 0xFFFFFFFFu : lazy_rank[u - lazy_base]; }
+    __device__ __forceinline__ uint32_t tie_of_unit(uint32_t u) const { return u == 0xFFFFFFFFu ? 0xFFFFFFFFu : lazy_key(u); }
     __device__ uint32_t tie(uint32_t i) const { return HAS_TIE ? (LAZY_ONLY ? tie_of_unit(unit[i]) : tie_[i]) : unit[i]; }
 
     // one compare-exchange of the merge network: the better entry goes to slot lo
@@ -164,7 +176,7 @@ struct TopK {
             uint32_t tt = uu;
             if (HAS_TIE) {
                 tt = 0xFFFFFFFFu;
-                if (live) tt = (LAZY_ONLY || lazy_rank) ? lazy_rank[uu - lazy_base] : tie_[S + lane];
+                if (live) tt = (LAZY_ONLY || lazy_rank) ? lazy_key(uu) : tie_[S + lane];
             }
             uint32_t mm = live ? mat[S + lane] : 0u;
             // one compare-exchange stage: partner = lane ^ MASK, TOP = highest bit of MASK
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(64) void k_score(ScoreArgs a) {
                 s = acc[idx];
                 m = cnt[idx];
                 unit = base + idx;
-                tie = a.url_rank ? a.url_rank[unit] : unit + a.unit_base;
+                tie = a.url_rank ? rank_key(a.url_rank, a.rank_base, a.rank_shift, unit) : unit + a.unit_base;
             }
             tk.offer(has, score_key(s), tie, unit + a.unit_base, m, a.k);
         }
@@ -515,7 +527,7 @@ struct RegTopK {
     // the k-th best score is high and exact at every moment: bounds against it are worth their arithmetic
     static constexpr bool FILTER_MIDDLE_LISTS = true;
     static constexpr bool CAN_LAZY = false;
-    __device__ void set_lazy_ties(const uint32_t*, uint32_t) {}
+    __device__ void set_lazy_ties(const uint32_t*, uint32_t, uint32_t, uint32_t) {}
     __device__ void init(unsigned char*) {
         key = 0;
         unit = 0xFFFFFFFFu;
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
     TK tk;
     tk.init(topk_mem);
     constexpr bool LAZY = HAS_RANK && TK::CAN_LAZY;
-    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base);
+    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base, a.rank_base, a.rank_shift);
     uint32_t n_used = 0;
     uint32_t w_min = 0;
     double thr_seen = tk.thr_score;
@@ -872,7 +884,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
                         if (may_m) {
                             const bool may = lanes(may_m);
                             uint32_t tie = 0;
-                            if (may && !LAZY) tie = HAS_RANK ? a.url_rank[u[t][j]] : u[t][j] + a.unit_base;
+                            if (may && !LAZY) tie = HAS_RANK ? rank_key(a.url_rank, a.rank_base, a.rank_shift, u[t][j]) : u[t][j] + a.unit_base;
                             tk.offer(may, score_key(sc), tie, u[t][j] + a.unit_base, 1u, a.k);
                         }
                     }
@@ -975,7 +987,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_step(ScoreArgs a) 
             if (may_m) {
                 const bool may = lanes(may_m);
                 uint32_t tie = 0;
-                if (may && !LAZY) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
+                if (may && !LAZY) tie = HAS_RANK ? rank_key(a.url_rank, a.rank_base, a.rank_shift, unit) : unit + a.unit_base;
                 tk.offer(may, score_key(s), tie, unit + a.unit_base, m, a.k);
             }
             __builtin_amdgcn_wave_barrier();
@@ -1161,7 +1173,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
     TK tk;
     tk.init(topk_mem);
     constexpr bool LAZY = HAS_RANK && TK::CAN_LAZY;
-    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base);
+    if (LAZY) tk.set_lazy_ties(a.url_rank, a.unit_base, a.rank_base, a.rank_shift);
     uint32_t w_min = 0;
     double thr_seen = tk.thr_score;
     uint32_t F_prev = 0;
@@ -1174,7 +1186,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void k_score_join(ScoreArgs a) 
     auto offer = [&](uint64_t may_m, double sc, uint32_t unit, uint32_t m) __attribute__((always_inline)) {
         const bool may = lanes(may_m);
         uint32_t tie = 0;
-        if (may && !LAZY) tie = HAS_RANK ? a.url_rank[unit] : unit + a.unit_base;
+        if (may && !LAZY) tie = HAS_RANK ? rank_key(a.url_rank, a.rank_base, a.rank_shift, unit) : unit + a.unit_base;
         tk.offer(may, score_key(sc), tie, unit + a.unit_base, m, a.k);
     };
 

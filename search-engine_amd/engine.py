@@ -243,10 +243,15 @@ class SearchEngine:
                 self._update_dirty = False
                 # explicit ranks only once a unit's index is no longer its place in url order (docs or articles were
                 # appended, a url changed): until then ties break on the index and searches skip the rank gather
-                if ex.n_docs and not self._doc_ranker.identity:
-                    ix.set_url_rank(SRC_WEB, self._doc_ranker.ranks())
-                if ex.n_articles and not self._art_ranker.identity:
-                    ix.set_url_rank(SRC_NEWS, self._art_ranker.ranks())
+                # (while the units of the last rebuild still stand in url order, only the appended ones get a key from memory)
+                for source, n_units, ranker in ((SRC_WEB, ex.n_docs, self._doc_ranker), (SRC_NEWS, ex.n_articles, self._art_ranker)):
+                    if not n_units or ranker.identity:
+                        continue
+                    sparse = ranker.appended_keys() if hasattr(ix, "set_url_rank_appended") else None
+                    if sparse is not None:
+                        ix.set_url_rank_appended(source, *sparse)
+                    else:
+                        ix.set_url_rank(source, ranker.ranks())
                 inf = ix.info() if hasattr(ix, "info") else None
                 held = max(inf.n_rows + inf.n_dead_rows, 1) if inf is not None else 1
                 if inf is not None and (inf.n_update_rows > self.COMPACT_UPDATE_FRACTION * held or

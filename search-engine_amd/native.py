@@ -69,7 +69,7 @@ class CorpusSpec(C.Structure):
 EXPORTS = [
     "sebm25_create", "sebm25_destroy", "sebm25_last_error", "sebm25_set_stream", "sebm25_build_local",
     "sebm25_local_stats", "sebm25_finalize", "sebm25_build", "sebm25_update", "sebm25_update_local", "sebm25_compact", "sebm25_get_stats", "sebm25_get_doc_len",
-    "sebm25_set_idf", "sebm25_set_url_rank", "sebm25_set_unit_base", "sebm25_get_info", "sebm25_get_postings",
+    "sebm25_set_idf", "sebm25_set_url_rank", "sebm25_set_url_rank_appended", "sebm25_set_unit_base", "sebm25_get_info", "sebm25_get_postings",
     "sebm25_search", "sebm25_search_noalloc", "sebm25_merge_topk", "sebm25_get_timings", "sebm25_enable_timing", "sebm25_zipf_cdf",
     "sebm25_gen_corpus", "sebm25_gen_queries",
 ]
@@ -113,6 +113,7 @@ def lib():
     L.sebm25_get_doc_len.argtypes = [vp, vp]
     L.sebm25_set_idf.argtypes = [vp, vp, vp]
     L.sebm25_set_url_rank.argtypes = [vp, i32, vp]
+    L.sebm25_set_url_rank_appended.argtypes = [vp, i32, u32, u32, vp, u32]
     L.sebm25_set_unit_base.argtypes = [vp, u32, u32]
     L.sebm25_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.sebm25_get_postings.argtypes = [vp, vp, vp, vp, vp]
@@ -328,6 +329,13 @@ class Index:
     def set_url_rank(self, source: int, rank):
         _check_dtype(rank, "rank", np.uint32)
         self._check(self._L.sebm25_set_url_rank(self._h, source, _addr(rank)))
+
+    def set_url_rank_appended(self, source: int, n_base: int, shift: int, keys):
+        """Tie-break keys for an index whose first n_base units are numbered in url order: (unit + 1) << shift for
+        those, keys[i] for unit n_base + i (sebm25_set_url_rank_appended)."""
+        _check_dtype(keys, "keys", np.uint32)
+        n_keys = int(keys.numel() if hasattr(keys, "numel") else len(keys))
+        self._check(self._L.sebm25_set_url_rank_appended(self._h, source, int(n_base), int(shift), _addr(keys), n_keys))
 
     def set_unit_base(self, web_base: int = 0, news_base: int = 0):
         self._check(self._L.sebm25_set_unit_base(self._h, web_base, news_base))

@@ -146,6 +146,9 @@ class UrlRanker:
         else:
             self.order = np.argsort(url_ranks(self.urls, key), kind="stable").astype(np.int64)
         self.identity = presorted           # rank == unit index: the index needs no rank array
+        # the first n_base units were numbered in url order; as long as none of them moves (a unit whose url is dropped keeps
+        # its place: it has no postings left to rank), only the units appended since need a key of their own (appended_keys)
+        self.n_base = n if presorted else 0
 
     def _k(self, i):
         u = self.urls[i]
@@ -156,6 +159,8 @@ class UrlRanker:
         -> whether any rank changed."""
         moved = [i for i, u in changed.items() if self.urls[i] != u]
         for i in moved:
+            if i < self.n_base and changed[i] is not None:
+                self.n_base = 0             # a base unit goes somewhere else in url order: every unit needs its rank
             self.urls[i] = changed[i]
         first_new = len(self.urls)
         self.urls.extend(appended)
@@ -185,6 +190,35 @@ class UrlRanker:
         rank = np.empty(len(self.order), np.uint32)
         rank[self.order] = np.arange(len(self.order), dtype=np.uint32)
         return rank
+
+    def appended_keys(self, max_shift: int = 8):
+        """-> (n_base, shift, keys) when the first n_base units still stand in url order among themselves: tie-break
+        keys that order all units as ranks() does, with (unit + 1) << shift for a base unit (no array needed) and keys[i]
+        for unit n_base + i, a value between the keys of the base units its url falls between.  None when a base unit
+        moved, or when more units fell into one gap than 2^shift - 1 keys."""
+        n, nb = len(self.order), self.n_base
+        if nb == 0:
+            return None
+        shift = max_shift
+        while shift > 0 and ((nb + 1) << shift) > 0xFFFFFFFF:
+            shift -= 1
+        if shift == 0:
+            return None
+        keys = np.zeros(n - nb, np.uint32)
+        gap, r = 0, 0                                   # base units seen so far, appended units since the last one
+        for u in self.order.tolist():
+            if u < nb:
+                if self.urls[u] is None:
+                    continue                            # dropped: stands at the end of the order, ranks nothing
+                if u + 1 <= gap:
+                    return None                         # base units out of order (cannot happen while n_base is kept)
+                gap, r = u + 1, 0
+            else:
+                r += 1
+                if r >= (1 << shift):
+                    return None
+                keys[u - nb] = (gap << shift) + r
+        return nb, shift, keys
 
 
 def _copy_in_text(terms, df, idf, avgdl, rows_per_block: int = 1 << 16):

@@ -154,6 +154,42 @@ def test_url_ranks_with_every_size_of_candidate_storage(built, tpq):
         ix.set_url_rank(se.SRC_NEWS, None)
 
 
+def test_keys_without_an_array_for_the_base_units_order_like_full_ranks(gpu_index_factory):
+    """sebm25_set_url_rank_appended: (unit + 1) << shift for the first n_base units, an array only for the rest.  Same
+    results as the full rank array that orders the units the same way, for every kernel form and candidate storage."""
+    c = small_corpus(n_docs=3000, n_terms=600, n_articles=0, body_min=5, body_max=12)   # few terms, small weights: many equal scores
+    ix = gpu_index_factory()
+    gpu_build(ix, c)
+    n, nb, shift = 3000, 2600, 6
+    rng = np.random.default_rng(11)
+    # the appended units fall into random gaps between the base units (several into some gaps, a few before the first)
+    gaps = np.sort(rng.integers(0, nb + 1, n - nb))
+    gaps[:3] = 0
+    keys = np.zeros(n - nb, np.uint32)
+    seen = {}
+    for i, g in enumerate(gaps.tolist()):
+        seen[g] = seen.get(g, 0) + 1
+        keys[i] = (g << shift) + seen[g]
+    keys = keys[rng.permutation(n - nb)]
+    full = np.concatenate([(np.arange(nb, dtype=np.uint64) + 1 << shift).astype(np.uint32), keys])
+    ranks = np.empty(n, np.uint32)
+    ranks[np.argsort(full, kind="stable")] = np.arange(n, dtype=np.uint32)
+    qs = [np.array(q, np.uint32) for q in ([0], [1, 2], [0, 3, 5], [2, 4, 6, 9], [1, 2, 3, 4, 5, 6], list(range(12)))]
+    for k in (7, 60, 200, 600):
+        ix.set_url_rank(se.SRC_WEB, ranks)
+        ref = ix.search(qs, k)
+        ix.set_url_rank_appended(se.SRC_WEB, nb, shift, keys)
+        got = ix.search(qs, k)
+        for key in ("count", "unit", "matched"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f"k {k} {key}")
+        np.testing.assert_array_equal(got["score"].view(np.uint64), ref["score"].view(np.uint64))
+    with pytest.raises(se.Sebm25Error):
+        ix.set_url_rank_appended(se.SRC_WEB, nb, shift, keys[:-1])       # must cover every unit
+    with pytest.raises(se.Sebm25Error):
+        ix.set_url_rank_appended(se.SRC_WEB, nb, 20, keys)               # shift too large
+    ix.set_url_rank(se.SRC_WEB, None)
+
+
 def test_sliced_long_queries_equal_unsliced(gpu_index_factory):
     # head terms over a larger corpus force the unit-range split + merge path
     c = small_corpus(n_docs=40_000, n_terms=3000, body_min=20, body_max=60, title_len=2, desc_len=4)

@@ -78,6 +78,10 @@ class OracleBackedIndex:
     def set_url_rank(self, source, rank):
         self.rank[source] = rank
 
+    def set_url_rank_appended(self, source, n_base, shift, keys):
+        self.rank[source] = np.concatenate([(np.arange(n_base, dtype=np.uint64) + 1 << shift).astype(np.uint32),
+                                            np.asarray(keys, np.uint32)])
+
     def set_idf(self, idf, present=None):
         self.orc.set_idf(idf, present)
 
@@ -716,6 +720,40 @@ def test_intent_score_with_cached_text_features_equals_the_formula_built_from_th
                 if hits[field] == len(ctx["query_words"]):
                     want += all_bonus
         assert got == want, (q, title, desc, url)
+
+
+def test_url_ranker_keys_for_appended_units_order_like_full_ranks():
+    """Keys that need no array for the units of the last rebuild ((unit + 1) << shift) and one key per appended unit:
+    the same order as the ranks of a full sort, through appends, re-crawls, dropped units; a base unit that moves
+    ends it."""
+    from search_engine_amd.store import UrlRanker
+
+    rng = np.random.default_rng(5)
+    urls = sorted(f"https://h{int(x):05d}.example/p" for x in rng.choice(90000, 400, replace=False))
+    r = UrlRanker(urls, presorted=True)
+    nb0, shift0, keys0 = r.appended_keys()
+    assert (nb0, shift0, len(keys0)) == (400, 8, 0)
+    for round_ in range(6):
+        new = [f"https://h{int(x):05d}.example/q{round_}" for x in rng.integers(0, 90000, 30)] + ["https://a.example/first"] * (round_ == 0)
+        dropped = {int(i): None for i in rng.choice(len(r.urls), 5, replace=False)}
+        r.apply(dropped, new)
+        nb, shift, keys = r.appended_keys()
+        assert nb == 400 and shift == 8 and len(keys) == len(r.urls) - 400
+        full = np.concatenate([(np.arange(nb, dtype=np.uint64) + 1 << shift).astype(np.uint32), keys])
+        live = np.array([u is not None for u in r.urls])
+        ranks = r.ranks()
+        order_by_key = np.argsort(full[live], kind="stable")
+        order_by_rank = np.argsort(ranks[live], kind="stable")
+        np.testing.assert_array_equal(order_by_key, order_by_rank)
+        assert len(set(full[live].tolist())) == int(live.sum())          # keys are distinct
+    # 300 units into one gap: more than 255 keys
+    r2 = UrlRanker(urls, presorted=True)
+    r2.apply({}, [f"{urls[10]}/{i:04d}" for i in range(300)])
+    assert r2.appended_keys() is None and not r2.identity
+    # a base unit whose url changes moves: every unit needs its rank again
+    r3 = UrlRanker(urls, presorted=True)
+    r3.apply({3: "https://zzz.example/"}, ["https://h00000.example/x"])
+    assert r3.appended_keys() is None
 
 
 def test_url_ranker_keeps_the_ranks_of_a_full_sort():
