@@ -416,9 +416,16 @@ def main():
         df_local, _ = q_ix.local_stats()
         sum_df = int(df_local.astype(np.int64)[qs.reshape(-1)].sum())
 
-        def run_queries(k, steps, with_rank=True):
+        def run_queries(k, steps, with_rank=True, appended_keys=False):
             # (through the sharded index when there is one: the exchange carries tie-break keys only when ranks are set)
-            (q_sharded if q_sharded is not None else q_ix).set_url_rank(se.SRC_WEB, ident if with_rank else None)
+            if appended_keys:
+                # the index after updates that appended 1 % of its docs: keys that need no array for the rest, the appended
+                # docs spread evenly over the url order (sebm25_set_url_rank_appended)
+                nb = q_docs - q_docs // 100
+                gaps = torch.arange(q_docs - nb, dtype=torch.int64, device=dev) * nb // max(q_docs - nb, 1)
+                q_ix.set_url_rank_appended(se.SRC_WEB, nb, 8, ((gaps << 8) + 1).to(torch.int32))
+            else:
+                (q_sharded if q_sharded is not None else q_ix).set_url_rank(se.SRC_WEB, ident if with_rank else None)
             res = {key: torch.empty((args.queries, k), dtype=dt, device=dev) for key, dt in
                    (("unit", torch.int32), ("score", torch.float64), ("matched", torch.int32), ("tie", torch.int32))}
             res["count"] = torch.empty(args.queries, dtype=torch.int32, device=dev)
@@ -483,6 +490,11 @@ def main():
                 q4_ms, q4ph = run_queries(args.k2, max(3, args.query_steps // 4), with_rank=True)
                 out["query"]["variant_with_url_ranks"]["candidate_limit_run"] = {"k": args.k2, "ms_per_batch": q4_ms,
                                                                                 "score_ms": q4ph.get("score_topk")}
+                if world == 1:
+                    q5_ms, q5ph = run_queries(args.k2, max(3, args.query_steps // 4), appended_keys=True)
+                    out["query"]["variant_with_url_ranks"]["keys_for_appended_docs_only"] = {
+                        "k": args.k2, "ms_per_batch": q5_ms, "score_ms": q5ph.get("score_topk"),
+                        "note": "1 % of the docs appended since the last rebuild: (unit + 1) << 8 for the others, no array read"}
         if world == 1 and q_ix is not ix:
             q_ix.close()
 
