@@ -5,9 +5,11 @@ set -e
 cd "$(dirname "$0")/../../search-engine_amd/csrc"
 name=$1; shift
 tmp=$(mktemp -d)
+pids=()
 for f in abi build_kernels query_kernels update_kernels corpus_gen; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=1000000 "$@" -c $f.hip -o $tmp/$f.o &
+  pids+=($!)
 done
-wait
+for p in "${pids[@]}"; do wait $p || { echo "error: a source file did not compile: no library written"; rm -rf $tmp; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/lib/libsebm25_$name.so $tmp/*.o
 rm -rf $tmp
